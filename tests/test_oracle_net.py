@@ -1,0 +1,78 @@
+"""CPU: the C oracle's network (oracle/vnect_net.c) against an independent torch float64 restatement."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests import torch_net
+from vnect_amd import weights as W
+
+
+def _frame_batch(seed, S=1):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 256, (S, 368, 368, 3)).astype(np.float32) / 255 - 0.4).astype(np.float32)
+
+
+def test_schema_counts():
+    sc = W.schema()
+    assert len(sc) == 109  # 109 TF variables
+    assert sum(int(np.prod(s)) for _, s in sc) == 14615936
+    w = W.synthetic_weights()
+    W.check_schema(w)
+    w2 = W.synthetic_weights()
+    assert all(np.array_equal(w[k], w2[k]) for k in w)  # bit-reproducible
+    assert abs(float(w["conv1/weights"].max()) - np.sqrt(6 / 147)) < 1e-3
+
+
+def test_sgemm_matches_numpy():
+    rng = np.random.default_rng(1)
+    for (M, N, K) in [(7, 5, 3), (100, 33, 300), (529, 84, 128), (97, 191, 1024)]:
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = rng.standard_normal((K, N)).astype(np.float32)
+        Cm = np.empty((M, N), np.float32)
+        f = oracle.oracle.c_f32p
+        oracle.lib().vo_sgemm(M, N, K, A.ctypes.data_as(f), K, B.ctypes.data_as(f), N, Cm.ctypes.data_as(f), N)
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        bound = (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)).max()
+        assert np.abs(Cm - ref).max() <= 2e-6 * bound
+
+
+@pytest.mark.parametrize("paper", [False, True])
+def test_network_vs_torch_f64(weights, paper):
+    batch = _frame_batch(7)
+    net = oracle.Oracle(weights, keep=True, paper_res2c=paper)
+    out = net.forward(batch)
+    taps = {}
+    with torch.no_grad():
+        ref = torch_net.forward(weights, batch, paper_res2c=paper, taps=taps).numpy()
+    assert out.shape == (1, 46, 46, 84)
+    # fp32 oracle vs f64: SURVEY 8(c) tolerance 1e-4 * max|map|; measured ~1e-6
+    assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max()
+    # every stage, not only the end
+    for name, t in taps.items():
+        a = net.activation(name)
+        t = t.numpy()
+        assert a.shape == t.shape, name
+        assert np.abs(a - t).max() <= 2e-5 * max(np.abs(t).max(), 1e-6), name
+    # layer shapes of the caffe blob dump (materials/caffe_script.ipynb cell 3): 368->184->92->46->23->46
+    assert net.activation("conv1").shape == (1, 184, 184, 64)
+    assert net.activation("pool1").shape == (1, 92, 92, 64)
+    assert net.activation("res3a_branch1").shape == (1, 46, 46, 512)
+    assert net.activation("res4a_branch1").shape == (1, 23, 23, 1024)
+    assert net.activation("res5c_branch2a_feat").shape == (1, 46, 46, 212)
+
+
+def test_res2c_quirk_matters(weights):
+    batch = _frame_batch(3)
+    a = oracle.Oracle(weights).forward(batch)
+    b = oracle.Oracle(weights, paper_res2c=True).forward(batch)
+    assert np.abs(a - b).max() > 1e-3  # the wiring changes the result; default follows vnect_model.py:56
+
+
+def test_batch_rows_independent(weights):
+    """S images are independent through the net (what pyramid sharding relies on)."""
+    batch = _frame_batch(11, S=2)
+    net = oracle.Oracle(weights)
+    both = net.forward(batch)
+    one = net.forward(batch[1:2])
+    assert np.array_equal(both[1:2], one)
