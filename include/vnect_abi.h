@@ -1,0 +1,150 @@
+/*
+ * vnect_abi.h -- C ABI of libvnect_hip.so, the MI355X (gfx950) VNect inference path.
+ *
+ * Drop-in boundary.  In the reference (XinArkh/VNect, paths relative to /root/reference) the
+ * per-frame path is src/estimator.py:97-142 (VNectEstimator.__call__); its only native boundary
+ * is tf.Session.run at src/estimator.py:100-104.  This library replaces that call AND the Python
+ * pre/post-processing around it, so the host keeps one call per frame.  Every entry point cites
+ * the reference code it replaces.  Plain C types only; caller owns every host pointer (valid only
+ * for the duration of the call); the library owns all device memory, streams, graphs and the
+ * OneEuro filter state (one handle == one video stream == one GPU).
+ *
+ * Conventions: every int-returning function returns VNECT_OK (0) or a negative VNECT_E_* code;
+ * no C++ exception crosses the boundary; vnect_last_error() gives the message.  Calls on one
+ * handle must be serialised by the caller; different handles are independent.
+ */
+#ifndef VNECT_ABI_H
+#define VNECT_ABI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNECT_ABI_VERSION 1
+#define VNECT_MAX_SCALES 8
+#define VNECT_BOX 368      /* src/estimator.py:19 box_size   */
+#define VNECT_HM 46        /* box_size / hm_factor (:21)     */
+#define VNECT_JOINTS 21    /* src/estimator.py:23 joints_sum */
+
+enum {
+    VNECT_OK = 0,
+    VNECT_E_ARG = -1,       /* bad argument / shape / name                          */
+    VNECT_E_STATE = -2,     /* call order (e.g. infer before finalize)              */
+    VNECT_E_HIP = -3,       /* HIP runtime error (message has hipGetErrorString)    */
+    VNECT_E_NODEVICE = -4,  /* no usable gfx950 device                              */
+    VNECT_E_TIMESTAMP = -5, /* timestamp equals the previous one: the reference raises
+                               ZeroDivisionError at src/OneEuroFilter.py:66          */
+    VNECT_E_COMM = -6       /* RCCL error                                           */
+};
+
+enum { VNECT_FP32 = 0, VNECT_BF16 = 1 };
+
+typedef struct vnect_handle vnect_handle;
+
+typedef struct vnect_config {
+    int32_t struct_size;              /* = sizeof(vnect_config)                                   */
+    int32_t device;                   /* HIP device ordinal                                       */
+    int32_t num_scales;               /* len(self.scales), src/estimator.py:32                    */
+    double scales[VNECT_MAX_SCALES];  /* each in (0, 1]                                           */
+    int32_t precision;                /* VNECT_FP32 | VNECT_BF16                                  */
+    int32_t paper_res2c;              /* 0 = reference wiring src/vnect_model.py:56 (default)     */
+    int32_t use_graph;                /* 1 = replay the frame as one hipGraph                     */
+    int32_t numpy_promotion;          /* float32-fed 3-D filters: 0 = numpy 1.x rules (the only
+                                         numpy TF1 runs with), 1 = NEP 50 (numpy >= 2)            */
+    int32_t max_frame_bytes;          /* capacity of one resident frame slot; 0 -> 4096*4096*3     */
+    int32_t num_frame_slots;          /* resident frame slots (>=1); 0 -> 4                        */
+} vnect_config;
+
+/* Replaces VNectEstimator.__init__ (src/estimator.py:27-68): session + graph + 42 + 63 filters. */
+int vnect_create(const vnect_config* cfg, vnect_handle** out);
+void vnect_destroy(vnect_handle* h);
+/* Message of the last failure on h (h == NULL: last vnect_create failure). Never NULL. */
+const char* vnect_last_error(vnect_handle* h);
+int vnect_abi_version(void);
+
+/* Replaces VNect.load_weights / assign_weights_from_dict (src/vnect_model.py:219-236).
+ * name is a key of the reference's pickle schema (src/caffe2pkl.py:51-80), e.g.
+ * "conv1/weights" (kh,kw,Cin,Cout), "conv1/biases", "res5c_branch1a/kernel" (kh,kw,Cout,Cin),
+ * "bn5c_branch2a/gamma".  Data is copied.  All 109 arrays must be set before vnect_finalize. */
+int vnect_set_weight(vnect_handle* h, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Packs weights into kernel layouts, uploads them, plans buffers, builds the launch sequence.
+ * (The reference's counterpart is saver.restore, src/estimator.py:55-60.) */
+int vnect_finalize(vnect_handle* h);
+
+/* `self.scales = [...]` (src/estimator.py:32 is a plain attribute callers may overwrite). */
+int vnect_set_scales(vnect_handle* h, const double* scales, int num_scales);
+
+/* Replaces sess.run([heatmap,x,y,z], {input: batch}) (src/estimator.py:100-104):
+ * batch (S,368,368,3) f32 NHWC -> out (S,46,46,84) f32, channels [hm | x | y | z] x 21
+ * (the tf.split at src/vnect_model.py:216-217 is a view of this tensor). S = num_scales. */
+int vnect_forward(vnect_handle* h, const float* batch_nhwc, int num_images, float* out_maps);
+
+/* Replaces VNectEstimator.gen_input_batch (src/estimator.py:70-81) on the device.
+ * bgr: (H,W,3) uint8, row_stride bytes per row.  batch_out may be NULL (batch stays on device). */
+int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, float* batch_out,
+                     double* scaler, int32_t* offset_x, int32_t* offset_y);
+
+/* Replaces src/estimator.py:105-139 (multi-scale merge, extract_2d_joints, joint_filter,
+ * extract_3d_joints, joint_filter, un-mapping) for maps supplied by the caller.
+ * t2d / t3d stand for the two time.time() reads at src/estimator.py:84. */
+int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d, double scaler, int32_t offset_x,
+                      int32_t offset_y, double* joints_2d /*21x2 [row,col]*/, float* joints_3d /*21x3*/);
+
+/* Replaces VNectEstimator.__call__ (src/estimator.py:97-142) end to end. */
+int vnect_infer(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, double t2d, double t3d,
+                double* joints_2d, float* joints_3d);
+
+/* Frames resident in HBM (throughput measurement; a capture pipeline that DMA-writes frames).
+ * upload copies a frame into slot; infer_resident runs __call__ on it without a host->device copy. */
+int vnect_upload_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride);
+int vnect_infer_resident(vnect_handle* h, int slot, double t2d, double t3d, double* joints_2d, float* joints_3d);
+/* Two-deep pipelining of the same call: submit enqueues a frame, collect waits for the oldest
+ * un-collected one (FIFO).  At most 2 frames may be in flight. */
+int vnect_submit_resident(vnect_handle* h, int slot, double t2d, double t3d);
+int vnect_collect(vnect_handle* h, double* joints_2d, float* joints_3d);
+
+/* New filters, as constructing a fresh VNectEstimator would (src/estimator.py:46-52). */
+int vnect_reset_filters(vnect_handle* h);
+
+/* Layer output of the last vnect_forward / vnect_infer, by reference scope name ("conv1", "pool1",
+ * "res2a_branch2a", block outputs "res2a".."res5a", "res5c_branch2a_feat", "res5c_branch2c", ...).
+ * Writes N,H,W,C to shape4 and up to capacity floats (dense NHWC, padding channels stripped).
+ * Parity/debug aid; not on the hot path. */
+int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t capacity, int32_t* shape4);
+
+typedef struct vnect_timings {
+    int32_t struct_size;
+    int32_t frames;            /* frames since the last vnect_reset_timings                     */
+    double total_ms;           /* HIP-event time, first kernel .. last kernel of each frame      */
+    double net_ms;             /* of which the conv stack (a1-a7)                                 */
+    double pre_ms, post_ms;    /* input pyramid; merge + joints                                   */
+    int32_t conv_launches;     /* conv-type kernel launches per frame                             */
+    double conv_flops;         /* algorithmic conv FLOPs per frame (2*MAC, live graph)            */
+} vnect_timings;
+/* Event timing is collected only on the non-graph path (use_graph=0) or when profiling is on. */
+int vnect_set_profiling(vnect_handle* h, int on);
+int vnect_get_timings(vnect_handle* h, vnect_timings* out);
+int vnect_reset_timings(vnect_handle* h);
+
+/* Per-layer launch plan: fills name (<=63 chars + NUL) and the numbers for layer idx; returns
+ * VNECT_E_ARG when idx is past the last layer. */
+typedef struct vnect_layer_info {
+    char name[64];
+    int32_t M, N, K;           /* implicit-GEMM view                                              */
+    int32_t tile_m, tile_n, split_k, workgroups;
+    double flops;              /* algorithmic                                                     */
+    double last_ms;            /* HIP-event time of the last profiled run (0 if none)             */
+} vnect_layer_info;
+int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out);
+
+/* Pyramid sharding over RCCL (one scale per rank): rank r runs the pre-processing and
+ * the conv stack for scale r only, the (46,46,84) maps are all-gathered, every rank finishes
+ * the post-processing.  unique_id is an ncclUniqueId (128 bytes) created by rank 0 with
+ * vnect_comm_unique_id and distributed by the host (torch.distributed / MPI / files). */
+int vnect_comm_unique_id(void* id128);
+int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads, exports every symbol the header declares, and fails loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from vnect_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vnect_abi.h")).read()
+    declared = set(re.findall(r"\b(vnect_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vnect_handle", "vnect_config", "vnect_timings", "vnect_layer_info"}
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    L = _native.lib()  # getattr on every symbol happens inside
+    assert L.vnect_abi_version() == 1
+
+
+def test_header_cites_reference_lines():
+    hdr = open(os.path.join(ROOT, "include", "vnect_abi.h")).read()
+    for fn in ("vnect_forward", "vnect_infer", "vnect_preprocess", "vnect_postprocess", "vnect_set_weight"):
+        pos = hdr.index("int " + fn)
+        assert re.search(r"src/\w+\.py:\d+", hdr[max(0, pos - 900):pos]), fn
+
+
+def test_struct_sizes_match_header_layout():
+    import ctypes as C
+    assert C.sizeof(_native.Config) == 104
+    assert _native.Config.scales.offset == 16
+    assert C.sizeof(_native.LayerInfo) == 64 + 7 * 4 + 4 + 16
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_create_fails_loudly_without_gpu():
+    with pytest.raises(_native.VnectError) as e:
+        _native.Handle([1.0])
+    assert e.value.code in (_native.E_NODEVICE, _native.E_HIP)
+
+
+def test_bad_config_rejected():
+    import ctypes as C
+    L = _native.lib()
+    cfg = _native.Config()
+    cfg.struct_size = 7
+    h = C.c_void_p()
+    assert L.vnect_create(C.byref(cfg), C.byref(h)) == _native.E_ARG
+    assert b"struct_size" in L.vnect_last_error(None)
+
+
+def test_frame_validation():
+    with pytest.raises(ValueError):
+        _native._as_frame(np.zeros((4, 4, 3), np.float32))
+    crop = np.zeros((100, 100, 3), np.uint8)[10:50, 20:60]  # non-contiguous rows are passed through by stride
+    assert _native._as_frame(crop).strides[0] == 300

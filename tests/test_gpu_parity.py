@@ -1,0 +1,269 @@
+"""GPU (MI355X): parity of the HIP path, called through the C ABI, against the CPU oracle.
+
+Tolerances: conv stack fp32 vs oracle fp32: max|d| <= 1e-4 * max|map| (measured ~1e-6);
+pre-processing and post-processing on identical inputs: bit-exact; joints_2d equal or within the tie
+rule; joints_3d |d| <= 0.05 mm + 1e-4*|v|.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+BASELINE_SCALES = [1.0, 0.8, 0.6]
+T0 = 1.7e9
+
+
+def _native():
+    from vnect_amd import _native
+    return _native
+
+
+def _handle(scales, weights, **kw):
+    n = _native()
+    h = n.Handle(scales, **kw)
+    h.set_weights(weights)
+    h.finalize()
+    return h
+
+
+@pytest.fixture(scope="module")
+def h3(weights):
+    h = _handle(BASELINE_SCALES, weights)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def ref3(weights, oracle_net):
+    import oracle
+    return oracle.OracleEstimator(scales=BASELINE_SCALES, net=oracle_net)
+
+
+def _log(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(obj, f, indent=1)
+
+
+# ------------------------------------------------------------------------------------------ conv stack
+def test_conv_stack_every_layer(h3, oracle_net):
+    """a1-a7: every named activation of the HIP graph vs the oracle, S=3 at BASELINE scales."""
+    import oracle
+    from tests import helpers
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
+    ref = oracle_net.forward(batch)
+    out = h3.forward(batch)
+    rows, bad = [], []
+    names = [L["name"] for L in h3.layers()]
+    acts = ["conv1", "pool1"]
+    for n in names:
+        if n.endswith("_branch2c") or n == "res5a_branch2c_new":
+            acts.append(n.split("_")[0])      # block output resNx
+        elif n == "res5c_deconv":
+            continue
+        elif n == "res5c_bone_length":
+            acts.append("res5c_branch2a_feat")
+        elif n not in ("conv1", "pool1"):
+            acts.append(n)
+    for n in acts:
+        a, r = h3.activation(n), oracle_net.activation(n)
+        assert a.shape == r.shape, n
+        err = float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-12))
+        rows.append((n, list(a.shape), err))
+        if not err <= 1e-4:
+            bad.append((n, err))
+    _log("layer_errors.json", rows)
+    for r in rows:
+        print("%-24s %-20s rel err %.3g" % (r[0], r[1], r[2]))
+    assert not bad, "first mismatching layers: %r" % bad[:3]
+    assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4
+
+
+def test_conv_stack_batch_independent(h3, oracle_net):
+    """The S images are independent: permuting the batch permutes the output (what sharding relies on)."""
+    import oracle
+    from tests import helpers
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(99), BASELINE_SCALES)
+    a = h3.forward(batch)
+    b = h3.forward(batch[::-1].copy())
+    assert np.array_equal(a, b[::-1])
+    assert np.array_equal(a, h3.forward(batch))  # deterministic: bit-identical on a second run
+
+
+def test_single_scale_and_paper_wiring(weights):
+    """S=1 (reference's 'faster loops' hint) and the paper_res2c switch, vs the oracle."""
+    import oracle
+    from tests import helpers
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(5, smooth=True), [1.0])
+    for paper in (False, True):
+        h = _handle([1.0], weights, paper_res2c=paper)
+        ref = oracle.Oracle(weights, paper_res2c=paper).forward(batch)
+        out = h.forward(batch)
+        h.close()
+        assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4, paper
+
+
+# ------------------------------------------------------------------------------------------ pre-processing
+@pytest.mark.parametrize("shape,smooth", [((368, 368), False), ((538, 368), True), ((300, 500), True),
+                                          ((720, 1280), True), ((97, 61), False), ((368, 367), False)])
+@pytest.mark.parametrize("scales", [BASELINE_SCALES, [1, 0.85, 0.7]])
+def test_preprocess_bit_exact(weights, shape, smooth, scales):
+    """a10: gen_input_batch on the device == oracle, bit for bit (8-bit fixed-point bilinear + pad + /255-0.4)."""
+    import oracle
+    from tests import helpers
+    frame = helpers.synth_frame(hash(shape) & 0xFFF, shape[0], shape[1], smooth=smooth)
+    h = _handle(scales, weights)
+    batch, scaler, off = h.preprocess(frame)
+    rb, rs, roff = oracle.gen_input_batch(frame, scales)
+    h.close()
+    assert scaler == rs and off == roff
+    assert np.array_equal(batch, rb)
+
+
+def test_preprocess_strided_crop(h3):
+    """Callers pass crops of a larger frame (run_estimator_ps.py:87): row stride != 3*W."""
+    import oracle
+    from tests import helpers
+    big = helpers.synth_frame(3, 480, 640, smooth=True)
+    crop = big[40:400, 100:420]
+    b, s, off = h3.preprocess(crop)
+    rb, rs, roff = oracle.gen_input_batch(np.ascontiguousarray(crop), BASELINE_SCALES)
+    assert s == rs and off == roff and np.array_equal(b, rb)
+
+
+# ------------------------------------------------------------------------------------------ post-processing
+@pytest.mark.parametrize("promo", [0, 1])
+def test_postprocess_bit_exact_sequence(weights, promo):
+    """a12-a16 on identical maps over 6 frames (filters engaged, irregular dt): bit-exact vs the oracle."""
+    import oracle
+    from tests import helpers
+    h = _handle(BASELINE_SCALES, weights, numpy_promotion=promo)
+    ref = oracle.OracleEstimator(scales=BASELINE_SCALES, nep50=bool(promo))
+    t = T0
+    for k in range(6):
+        maps = helpers.synth_maps(300 + k, 3)
+        t += 1 / 30 + 0.003 * (k % 3)
+        a2, a3 = h.postprocess(maps, t, t + 0.0007, 368 / 538, 58, 0)
+        r2, r3 = ref.postprocess(maps, t, t + 0.0007, 368 / 538, 58, 0)
+        assert np.array_equal(a2, r2), k
+        assert np.array_equal(a3, r3), k
+    h.close()
+
+
+@pytest.mark.parametrize("case", ["pic_default", "wide_default", "square_baseline", "square_one_scale"])
+def test_postprocess_reproduces_reference_recordings(weights, case):
+    """The device pre+post-processing reproduces what the reference's own Python returned (fixtures F3)."""
+    from tests import helpers
+    with np.load(os.path.join(G, "glue_%s.npz" % case)) as z:
+        g = {k: z[k] for k in z.files}
+    scales = list(g["scales"])
+    if case == "pic_default":
+        from PIL import Image
+        pic = np.asarray(Image.open(os.path.join(G, "test_pic.jpg")).convert("RGB"))[:, :, ::-1].copy()
+        frames = [pic] * 3
+    elif case == "wide_default":
+        frames = [helpers.synth_frame(31 + k, 300, 500, smooth=True) for k in range(3)]
+    elif case == "square_baseline":
+        frames = [helpers.synth_frame(1234 + k) for k in range(4)]
+    else:
+        frames = [helpers.synth_frame(77, smooth=True)]
+    h = _handle(scales, weights, numpy_promotion=1)  # fixtures were recorded under numpy 2.x
+    for k, frame in enumerate(frames):
+        batch, scaler, (ox, oy) = h.preprocess(frame)
+        assert [scaler, ox, oy] == list(g["meta"][k])
+        assert np.array_equal(batch.astype(np.float64).sum(axis=(1, 2, 3)), g["batch_sum"][k])
+        assert np.array_equal(batch[:, ::37, ::41, :], g["batch_probe"][k])
+        maps = helpers.synth_maps(int(g["map_seed"]) + k, len(scales))
+        j2, j3 = h.postprocess(maps, g["t2d"][k], g["t3d"][k], scaler, ox, oy)
+        assert np.array_equal(j2, g["joints_2d"][k]), k
+        assert np.array_equal(j3, g["joints_3d"][k]), k
+    h.close()
+
+
+def test_argmax_ties_and_planted_peaks(weights):
+    h = _handle([1.0], weights)
+    flat = np.zeros((1, 46, 46, 84), np.float32)
+    j2, j3 = h.postprocess(flat, T0, T0)
+    assert np.all(j2 == 0) and np.all(j3 == 0)  # first maximum in row-major order
+    hm = np.zeros((1, 46, 46, 84), np.float32)
+    yy, xx = np.mgrid[0:46, 0:46]
+    cells = [(3 + 2 * j, 40 - j) for j in range(21)]
+    for j, (cy, cx) in enumerate(cells):
+        hm[0, :, :, j] = np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.5 ** 2))
+    h.reset_filters()
+    j2, _ = h.postprocess(hm, T0, T0)
+    for j, (cy, cx) in enumerate(cells):
+        assert abs(j2[j, 0] - (cy * 8 + 3.5)) <= 0.5 and abs(j2[j, 1] - (cx * 8 + 3.5)) <= 0.5
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ end to end
+def test_end_to_end_vs_oracle(h3, ref3, oracle_net):
+    """Whole __call__ over 4 frames.  Heatmaps of random weights are noise-like, so joints_2d is gated by the
+    tie rule: equal, or the oracle's heatmap value at the GPU arg-max is within eps of its maximum."""
+    import oracle
+    from tests import helpers
+    h3.reset_filters()
+    ref3.reset()
+    worst3 = 0.0
+    for k in range(4):
+        frame = helpers.synth_frame(1234 + k, smooth=True)
+        t = T0 + k / 30
+        j2, j3 = h3.infer(frame, t, t + 0.001)
+        r2, r3 = ref3(frame, t, t + 0.001)
+        if k == 0:  # first frame: filters are the identity, joints_2d are raw arg-max positions
+            batch, _, _ = oracle.gen_input_batch(frame, BASELINE_SCALES)
+            avg = oracle.merge_scales(oracle_net.forward(batch), BASELINE_SCALES)[0]
+            for j in range(21):
+                if not np.array_equal(j2[j], r2[j]):
+                    up = oracle.resize(np.ascontiguousarray(avg[:, :, j]), 8.0)
+                    assert up[int(j2[j, 0]), int(j2[j, 1])] >= up.max() - 1e-4 * np.abs(avg).max(), j
+        same = np.all(np.abs(j2 - r2) <= 1e-6, axis=1)
+        d3 = np.abs(j3 - r3)[same]
+        tol = 0.05 + 1e-4 * np.abs(r3)[same]
+        worst3 = max(worst3, float((d3 - tol).max()) if d3.size else 0.0)
+        assert np.all(d3 <= tol), k
+        assert same.mean() >= 0.8, "too many arg-max flips: %d/21" % (21 - same.sum())
+    print("worst 3-D excess over tolerance:", worst3)
+
+
+def test_pipelined_submit_collect_equals_sequential(weights):
+    from tests import helpers
+    frames = [helpers.synth_frame(500 + k, smooth=True) for k in range(4)]
+    a = _handle(BASELINE_SCALES, weights)
+    b = _handle(BASELINE_SCALES, weights, use_graph=False)
+    for k, f in enumerate(frames):
+        a.upload_frame(k, f)
+        b.upload_frame(k, f)
+    seq = [b.infer_resident(k, T0 + k / 30, T0 + k / 30 + 0.001) for k in range(4)]
+    a.submit_resident(0, T0, T0 + 0.001)
+    got = []
+    for k in range(1, 4):
+        a.submit_resident(k, T0 + k / 30, T0 + k / 30 + 0.001)
+        got.append(a.collect())
+    got.append(a.collect())
+    for (g2, g3), (s2, s3) in zip(got, seq):
+        assert np.array_equal(g2, s2) and np.array_equal(g3, s3)  # graph replay == eager launches, bit for bit
+    a.close(), b.close()
+
+
+def test_errors_mirror_reference(weights):
+    from vnect_amd import VNectEstimator
+    est = VNectEstimator(scales=[1.0], weights=weights, verbose=False)
+    frame = np.zeros((368, 368, 3), np.uint8)
+    est(frame, timestamp=5.0)
+    with pytest.raises(ZeroDivisionError):   # OneEuroFilter.py:66
+        est(frame, timestamp=5.0)
+    with pytest.raises(ValueError):
+        est(np.zeros((368, 368), np.uint8))
+    j2, j3 = est(frame, timestamp=6.0)
+    assert j2.shape == (21, 2) and j2.dtype == np.float64 and j3.shape == (21, 3) and j3.dtype == np.float32
+    est.scales = [1.0, 0.7]   # assignable like the reference attribute
+    j2, j3 = est(frame, timestamp=7.0)
+    assert np.all(np.isfinite(j2))
+    est.close()

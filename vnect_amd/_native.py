@@ -1,0 +1,243 @@
+"""ctypes binding of libvnect_hip.so (include/vnect_abi.h).  No torch, no TensorFlow.
+
+The library is the product path; there is no CPU fallback: if it is missing or no MI355X is
+visible, loading / creating a handle raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvnect_hip.so")
+_lib = None
+
+MAX_SCALES = 8
+OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM = 0, -1, -2, -3, -4, -5, -6
+FP32, BF16 = 0, 1
+
+
+class VnectError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvnect_hip: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("num_scales", C.c_int32),
+                ("scales", C.c_double * MAX_SCALES), ("precision", C.c_int32), ("paper_res2c", C.c_int32),
+                ("use_graph", C.c_int32), ("numpy_promotion", C.c_int32), ("max_frame_bytes", C.c_int32),
+                ("num_frame_slots", C.c_int32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("frames", C.c_int32), ("total_ms", C.c_double), ("net_ms", C.c_double),
+                ("pre_ms", C.c_double), ("post_ms", C.c_double), ("conv_launches", C.c_int32),
+                ("conv_flops", C.c_double)]
+
+
+class LayerInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("split_k", C.c_int32), ("workgroups", C.c_int32),
+                ("flops", C.c_double), ("last_ms", C.c_double)]
+
+
+# every symbol include/vnect_abi.h declares: name -> (restype, argtypes)
+_f32p, _f64p, _u8p, _i32p = (C.POINTER(t) for t in (C.c_float, C.c_double, C.c_uint8, C.c_int32))
+_H = C.c_void_p
+SYMBOLS = {
+    "vnect_abi_version": (C.c_int, []),
+    "vnect_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "vnect_destroy": (None, [_H]),
+    "vnect_last_error": (C.c_char_p, [_H]),
+    "vnect_set_weight": (C.c_int, [_H, C.c_char_p, _f32p, C.POINTER(C.c_int64), C.c_int]),
+    "vnect_finalize": (C.c_int, [_H]),
+    "vnect_set_scales": (C.c_int, [_H, _f64p, C.c_int]),
+    "vnect_forward": (C.c_int, [_H, _f32p, C.c_int, _f32p]),
+    "vnect_preprocess": (C.c_int, [_H, _u8p, C.c_int, C.c_int, C.c_int64, _f32p, _f64p, _i32p, _i32p]),
+    "vnect_postprocess": (C.c_int, [_H, _f32p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _f64p, _f32p]),
+    "vnect_infer": (C.c_int, [_H, _u8p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, _f64p, _f32p]),
+    "vnect_upload_frame": (C.c_int, [_H, C.c_int, _u8p, C.c_int, C.c_int, C.c_int64]),
+    "vnect_infer_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, _f64p, _f32p]),
+    "vnect_submit_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
+    "vnect_collect": (C.c_int, [_H, _f64p, _f32p]),
+    "vnect_reset_filters": (C.c_int, [_H]),
+    "vnect_read_activation": (C.c_int, [_H, C.c_char_p, _f32p, C.c_int64, _i32p]),
+    "vnect_set_profiling": (C.c_int, [_H, C.c_int]),
+    "vnect_get_timings": (C.c_int, [_H, C.POINTER(Timings)]),
+    "vnect_reset_timings": (C.c_int, [_H]),
+    "vnect_get_layer_info": (C.c_int, [_H, C.c_int, C.POINTER(LayerInfo)]),
+    "vnect_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "vnect_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+}
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the library (works without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """Load the library; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libvnect_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(needs hipcc); the VNect path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype, fn.argtypes = res, args
+        if L.vnect_abi_version() != 1:
+            raise ImportError("libvnect_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Handle:
+    """Thin RAII wrapper over vnect_handle; every method maps 1:1 to a C entry point."""
+
+    def __init__(self, scales, device=0, precision=FP32, paper_res2c=False, use_graph=True, numpy_promotion=0,
+                 max_frame_bytes=0, num_frame_slots=0):
+        L = lib()
+        cfg = Config()
+        cfg.struct_size = C.sizeof(Config)
+        cfg.device = device
+        cfg.num_scales = len(scales)
+        for i, s in enumerate(scales):
+            cfg.scales[i] = float(s)
+        cfg.precision, cfg.paper_res2c, cfg.use_graph = precision, int(paper_res2c), int(use_graph)
+        cfg.numpy_promotion, cfg.max_frame_bytes, cfg.num_frame_slots = numpy_promotion, max_frame_bytes, num_frame_slots
+        h = _H()
+        rc = L.vnect_create(C.byref(cfg), C.byref(h))
+        self._h = h if h.value else None
+        self.num_scales = len(scales)
+        if rc:
+            msg = L.vnect_last_error(self._h).decode()
+            self.close()
+            raise VnectError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vnect_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc:
+            raise VnectError(rc, lib().vnect_last_error(self._h).decode())
+
+    def set_weights(self, weights):
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shp = (C.c_int64 * a.ndim)(*a.shape)
+            self._ck(lib().vnect_set_weight(self._h, name.encode(), _ptr(a, _f32p), shp, a.ndim))
+
+    def finalize(self):
+        self._ck(lib().vnect_finalize(self._h))
+
+    def set_scales(self, scales):
+        sc = np.asarray(scales, np.float64)
+        self._ck(lib().vnect_set_scales(self._h, _ptr(sc, _f64p), len(sc)))
+
+    def forward(self, batch):
+        batch = np.ascontiguousarray(batch, dtype=np.float32)
+        if batch.shape != (self.num_scales, 368, 368, 3):
+            raise ValueError("batch must be (%d,368,368,3)" % self.num_scales)
+        out = np.empty((self.num_scales, 46, 46, 84), np.float32)
+        self._ck(lib().vnect_forward(self._h, _ptr(batch, _f32p), self.num_scales, _ptr(out, _f32p)))
+        return out
+
+    def preprocess(self, img, want_batch=True):
+        img = _as_frame(img)
+        H, W = img.shape[:2]
+        batch = np.empty((self.num_scales, 368, 368, 3), np.float32) if want_batch else None
+        scaler, ox, oy = C.c_double(), C.c_int32(), C.c_int32()
+        self._ck(lib().vnect_preprocess(self._h, _ptr(img, _u8p), H, W, img.strides[0],
+                                        _ptr(batch, _f32p) if want_batch else None, C.byref(scaler), C.byref(ox),
+                                        C.byref(oy)))
+        return batch, scaler.value, [ox.value, oy.value]
+
+    def postprocess(self, maps, t2d, t3d, scaler=1.0, offset_x=0, offset_y=0):
+        maps = np.ascontiguousarray(maps, dtype=np.float32)
+        if maps.shape != (self.num_scales, 46, 46, 84):
+            raise ValueError("maps must be (%d,46,46,84)" % self.num_scales)
+        j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
+        self._ck(lib().vnect_postprocess(self._h, _ptr(maps, _f32p), t2d, t3d, scaler, offset_x, offset_y,
+                                         _ptr(j2, _f64p), _ptr(j3, _f32p)))
+        return j2, j3
+
+    def infer(self, img, t2d, t3d):
+        img = _as_frame(img)
+        H, W = img.shape[:2]
+        j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
+        self._ck(lib().vnect_infer(self._h, _ptr(img, _u8p), H, W, img.strides[0], t2d, t3d, _ptr(j2, _f64p),
+                                   _ptr(j3, _f32p)))
+        return j2, j3
+
+    def upload_frame(self, slot, img):
+        img = _as_frame(img)
+        H, W = img.shape[:2]
+        self._ck(lib().vnect_upload_frame(self._h, slot, _ptr(img, _u8p), H, W, img.strides[0]))
+
+    def infer_resident(self, slot, t2d, t3d):
+        j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
+        self._ck(lib().vnect_infer_resident(self._h, slot, t2d, t3d, _ptr(j2, _f64p), _ptr(j3, _f32p)))
+        return j2, j3
+
+    def submit_resident(self, slot, t2d, t3d):
+        self._ck(lib().vnect_submit_resident(self._h, slot, t2d, t3d))
+
+    def collect(self):
+        j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
+        self._ck(lib().vnect_collect(self._h, _ptr(j2, _f64p), _ptr(j3, _f32p)))
+        return j2, j3
+
+    def reset_filters(self):
+        self._ck(lib().vnect_reset_filters(self._h))
+
+    def activation(self, name):
+        shp = (C.c_int32 * 4)()
+        self._ck(lib().vnect_read_activation(self._h, name.encode(), None, 0, shp))
+        out = np.empty(tuple(shp), np.float32)
+        self._ck(lib().vnect_read_activation(self._h, name.encode(), _ptr(out, _f32p), out.size, shp))
+        return out
+
+    def set_profiling(self, on):
+        self._ck(lib().vnect_set_profiling(self._h, int(on)))
+
+    def timings(self):
+        t = Timings()
+        t.struct_size = C.sizeof(Timings)
+        self._ck(lib().vnect_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timings._fields_ if k != "struct_size"}
+
+    def reset_timings(self):
+        self._ck(lib().vnect_reset_timings(self._h))
+
+    def layers(self):
+        out, i = [], 0
+        while True:
+            li = LayerInfo()
+            if lib().vnect_get_layer_info(self._h, i, C.byref(li)):
+                return out
+            out.append({k: (getattr(li, k).decode() if k == "name" else getattr(li, k)) for k, _ in LayerInfo._fields_})
+            i += 1
+
+
+def _as_frame(img):
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("frame must be a uint8 (H, W, 3) BGR array")
+    if img.strides[2] != 1 or img.strides[1] != 3:
+        img = np.ascontiguousarray(img)  # row stride may stay arbitrary (crops of a larger frame)
+    return img

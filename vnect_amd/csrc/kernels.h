@@ -1,0 +1,135 @@
+// kernels.h -- argument blocks and launchers shared by the HIP kernels and the host runtime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vnect {
+
+constexpr int BOX = 368;
+constexpr int HM = 46;
+constexpr int NJ = 21;
+constexpr int MAPC = 84;       // 4 maps x 21 joints
+constexpr int ARG_SLABS = 8;   // row slabs per joint in the arg-max kernel (368 / 8 = 46 rows each)
+constexpr int MAX_TAPS = 16;
+
+// Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
+//   m = (s*Ho + oy)*Wo + ox, k = (tap, ci), A[m][k] = in[s][oy*stride + dy[tap]][ox*stride + dx[tap]][ci]
+struct ConvArgs {
+    const float* in;
+    const float* w;       // packed [phase][Npad][K], K contiguous
+    const float* bias;    // [Npad] (zeros when the layer has none)
+    const float* scale;   // [Npad] or nullptr: v = (acc + bias) * scale + shift
+    const float* shift;
+    const float* resid;   // nullptr or same pixel indexing as out
+    float* out;
+    float* ws;            // split-K workspace [ksplit][out pixels][Npad]
+    int S, H, W, Cs;      // input grid, floats per input pixel
+    int Ho, Wo, M;        // logical output grid, M = S*Ho*Wo
+    int K, ntaps, cpt;    // K = ntaps*cpt*32
+    int stride;
+    int Npad, Nvalid;
+    int ldc, ldr;         // floats per out / resid pixel
+    int OH, OW, os;       // out pixel = (s, oy*os + py, ox*os + px) in an (OH, OW) grid
+    int nphase;           // 1, or 4 for the transposed conv (py = phase>>1, px = phase&1)
+    int ksplit;
+    int relu_cols;        // ReLU on columns < relu_cols
+    int pixmode;          // conv1: a 32-float chunk is 8 consecutive NHWC4 pixels of one input row
+    long long w_phase_stride;
+    int8_t dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]
+};
+
+struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])
+    const float* ws;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const float* resid;
+    float* out;
+    long long npix;
+    int Npad, Nvalid, ldc, ldr, ksplit, relu_cols;
+};
+
+hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st);
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
+hipError_t conv_setup();  // one-time function attributes (dynamic LDS size)
+
+hipError_t launch_pad3to4(const float* in3, float* out4, long long npix, hipStream_t st);
+hipError_t launch_strip4to3(const float* in4, float* out3, long long npix, hipStream_t st);
+hipError_t launch_maxpool(const float* in, float* out, int S, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+hipError_t launch_bone(float* feat, long long npix, int ld, hipStream_t st);
+
+// ---- pre-processing -------------------------------------------------------------------
+struct ResizeTab {  // 8-bit bilinear tables for one destination axis pair (OpenCV fixed point, 11 bits)
+    int dh, dw;       // destination size
+    int xmax;         // columns >= xmax take S[sx]*2048 (right border)
+    int copy;         // destination size == source size: plain copy
+    int16_t sx[BOX], a0[BOX], a1[BOX];
+    int16_t sy0[BOX], sy1[BOX], b0[BOX], b1[BOX];
+};
+
+struct FrameParams {  // per frame, written by the host into pinned memory and copied in-stream
+    double t2d, t3d, scaler;
+    int offx, offy;
+    int H, W;
+    long long row_stride;
+    const uint8_t* frame;  // device pointer
+    int pad_;
+    ResizeTab sq;          // squarify resize (utils.img_scale_squarify)
+};
+
+struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.img_scale_padding)
+    int S;
+    int pad[8];     // leading pad rows/cols per scale
+    int scaled[8];  // 1: scale < 1 (resize + pad), 0: the square itself
+    ResizeTab t[8];
+    float lut[256]; // (float)v / 255 - 0.4 in float32
+};
+
+hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st);
+hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, hipStream_t st);
+
+// ---- post-processing ------------------------------------------------------------------
+struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale
+    int copy;
+    int sx[HM], edge[HM];     // edge: column >= xmax -> value is S[sx]
+    float a0[HM], a1[HM];
+    int sy0[HM], sy1[HM];
+    float b0[HM], b1[HM];
+};
+struct MergeTabs {
+    int S;
+    MergeTab t[8];
+};
+struct UpTab {  // x8 upsample tables (utils.extract_2d_joints)
+    int sx[BOX], edge[BOX];
+    double a0[BOX], a1[BOX];
+    int sy0[BOX], sy1[BOX];
+    double b0[BOX], b1[BOX];
+};
+struct ArgPartial {
+    double v;
+    int idx;
+    int pad_;
+};
+struct Filt {  // OneEuroFilter + its two LowPassFilters
+    double freq, mincutoff, beta, dcutoff;
+    double lasttime;
+    double x_y, x_s, dx_y, dx_s;
+    int has_last, x_init, dx_init, pad_;
+};
+struct FilterBank {
+    Filt f2[NJ][2];
+    Filt f3[NJ][3];
+};
+struct JointsOut {
+    double j2d[NJ * 2];
+    float j3d[NJ * 3];
+    int status;
+};
+
+hipError_t launch_merge(const float* maps, const MergeTabs* tabs, double* avg, int S, hipStream_t st);
+hipError_t launch_argmax(const double* avg, const UpTab* up, ArgPartial* part, hipStream_t st);
+hipError_t launch_joints(const ArgPartial* part, const double* avg, FilterBank* fb, const FrameParams* fp, int nep50,
+                         JointsOut* out, hipStream_t st);
+
+}  // namespace vnect

@@ -1,0 +1,1124 @@
+// runtime.cpp -- host side of libvnect_hip.so: handle, weight packing, launch plan, HIP graph, C ABI.
+// See include/vnect_abi.h for the boundary and the reference lines each entry point replaces.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vnect_abi.h"
+#include "kernels.h"
+
+using namespace vnect;
+
+namespace {
+
+std::string g_create_error = "";
+
+struct HostArray {
+    std::vector<float> d;
+    std::vector<int64_t> shape;
+};
+
+struct Tensor {
+    std::string name;
+    int S = 0, H = 0, W = 0, C = 0, Cs = 0;  // C valid channels, Cs floats per pixel
+    float* d = nullptr;
+    size_t floats() const { return (size_t)S * H * W * Cs; }
+};
+
+enum OpKind { OP_CONV, OP_POOL, OP_BONE };
+
+struct Layer {
+    OpKind op = OP_CONV;
+    std::string name;
+    int in = -1, resid = -1, out = -1;
+    ConvArgs a{};
+    ReduceArgs r{};
+    int BM = 64, BN = 64;
+    float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    int Nreal = 0, Kreal = 0;
+    double flops = 0;
+    float last_ms = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+constexpr int RING = 4;
+
+}  // namespace
+
+struct vnect_handle {
+    vnect_config cfg{};
+    int S = 0;
+    std::string err;
+    bool finalized = false;
+    hipStream_t st = nullptr;
+    std::map<std::string, HostArray> weights;
+    std::vector<Tensor> tensors;
+    std::vector<Layer> layers;
+    std::map<std::string, int> tensor_by_name;
+    int t_input4 = -1, t_out = -1;
+    float* in3 = nullptr;  // (S,368,368,3) staging for vnect_forward / preprocess read-back
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+    std::vector<void*> dev_allocs;
+    // pre/post
+    uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
+    struct SlotInfo { int H = 0, W = 0; long long stride = 0; };
+    std::vector<SlotInfo> slots;
+    uint8_t* sq = nullptr;
+    FrameParams* d_fp = nullptr;
+    FrameParams* h_fp[RING] = {};  // pinned
+    ScaleTabs* d_stabs = nullptr;
+    MergeTabs* d_mtabs = nullptr;
+    UpTab* d_up = nullptr;
+    double* d_avg = nullptr;
+    ArgPartial* d_part = nullptr;
+    FilterBank* d_fb = nullptr;
+    JointsOut* d_out = nullptr;
+    JointsOut* h_out[RING] = {};  // pinned
+    hipEvent_t done[RING] = {};
+    unsigned long long seq_submit = 0, seq_collect = 0;
+    bool have2 = false, have3 = false;
+    double last2 = 0, last3 = 0;
+    // cached squarify table
+    int sq_H = -1, sq_W = -1;
+    FrameParams sq_cache{};
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[4] = {};
+    vnect_timings tim{};
+    double conv_flops = 0;
+    int conv_launches = 0;
+    // comm
+    void* comm = nullptr;
+    int rank = 0, nranks = 1;
+    float* gather = nullptr;
+};
+
+namespace {
+
+int fail(vnect_handle* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCK(h, expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(h, VNECT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+template <typename T>
+int dev_alloc(vnect_handle* h, T** p, size_t count)
+{
+    void* q = nullptr;
+    HIPCK(h, hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16)));
+    h->dev_allocs.push_back(q);
+    *p = (T*)q;
+    return VNECT_OK;
+}
+
+template <typename T>
+int upload(vnect_handle* h, T** dst, const std::vector<T>& v)
+{
+    int rc = dev_alloc(h, dst, v.size());
+    if (rc) return rc;
+    HIPCK(h, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return VNECT_OK;
+}
+
+// ---- OpenCV INTER_LINEAR table builders (resize.cpp semantics) ----------------------
+int cv_round(double v) { return (int)nearbyint(v); }  // round half to even
+int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+int16_t sat_short(float v)
+{
+    int r = (int)nearbyintf(v);
+    return (int16_t)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+struct AxisTab {
+    std::vector<int> s0, s1, edge;
+    std::vector<float> f;
+    int xmax = 0;
+};
+// x axis: offset clamped and fraction zeroed at both borders; columns >= xmax use the single tap
+AxisTab axis_x(int ssize, int dsize, double scale)
+{
+    AxisTab t;
+    t.s0.resize(dsize), t.s1.resize(dsize), t.edge.resize(dsize), t.f.resize(dsize);
+    t.xmax = dsize;
+    for (int d = 0; d < dsize; d++) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) fx = 0, sx = 0;
+        if (sx + 1 >= ssize) {
+            t.xmax = std::min(t.xmax, d);
+            if (sx >= ssize - 1) fx = 0, sx = ssize - 1;
+        }
+        t.s0[d] = sx, t.s1[d] = std::min(sx + 1, ssize - 1), t.f[d] = fx;
+    }
+    for (int d = 0; d < dsize; d++) t.edge[d] = d >= t.xmax;
+    return t;
+}
+// y axis: floor + fraction kept; the two source rows are clipped into the image
+AxisTab axis_y(int ssize, int dsize, double scale)
+{
+    AxisTab t;
+    t.s0.resize(dsize), t.s1.resize(dsize), t.edge.assign(dsize, 0), t.f.resize(dsize);
+    for (int d = 0; d < dsize; d++) {
+        float fy = (float)((d + 0.5) * scale - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        t.s0[d] = clipi(sy, 0, ssize), t.s1[d] = clipi(sy + 1, 0, ssize), t.f[d] = fy;
+    }
+    return t;
+}
+
+// cv2.resize(u8 src (sh,sw), (0,0), fx=fy=f): destination size and fixed-point tables
+bool build_u8_tab(int sh, int sw, double f, ResizeTab* t)
+{
+    memset(t, 0, sizeof *t);
+    t->dw = cv_round(sw * f), t->dh = cv_round(sh * f);
+    if (t->dw < 1 || t->dh < 1 || t->dw > BOX || t->dh > BOX) return false;
+    t->copy = (t->dw == sw && t->dh == sh);
+    const double scale = 1.0 / f;
+    AxisTab x = axis_x(sw, t->dw, scale), y = axis_y(sh, t->dh, scale);
+    t->xmax = x.xmax;
+    for (int d = 0; d < t->dw; d++) {
+        t->sx[d] = (int16_t)x.s0[d];
+        t->a0[d] = sat_short((1.f - x.f[d]) * 2048.f);
+        t->a1[d] = sat_short(x.f[d] * 2048.f);
+    }
+    for (int d = 0; d < t->dh; d++) {
+        t->sy0[d] = (int16_t)y.s0[d], t->sy1[d] = (int16_t)y.s1[d];
+        t->b0[d] = sat_short((1.f - y.f[d]) * 2048.f);
+        t->b1[d] = sat_short(y.f[d] * 2048.f);
+    }
+    return true;
+}
+
+int build_scale_tables(vnect_handle* h)
+{
+    ScaleTabs st;
+    memset(&st, 0, sizeof st);
+    MergeTabs mt;
+    memset(&mt, 0, sizeof mt);
+    st.S = mt.S = h->S;
+    for (int v = 0; v < 256; v++) st.lut[v] = (float)v / 255.f - 0.4f;  // float32: batch / 255 - 0.4
+    for (int i = 0; i < h->S; i++) {
+        const double s = h->cfg.scales[i];
+        if (!(s > 0.0) || s > 1.0) return fail(h, VNECT_E_ARG, "scales must be in (0, 1]");
+        // estimator.py:77: `img_scale_padding(...) if scale < 1 else img_square`
+        st.scaled[i] = s < 1.0;
+        if (st.scaled[i]) {
+            if (!build_u8_tab(BOX, BOX, s, &st.t[i])) return fail(h, VNECT_E_ARG, "scale too small");
+            st.pad[i] = (BOX - st.t[i].dh) / 2;  // utils.py:137-140; the remainder pads the far side
+        }
+        // estimator.py:112-119: rescale = 1.0 / scale; cv2.resize(map, fx=fy=rescale); centre crop 46x46
+        const double f = 1.0 / s;
+        const int ds = cv_round(HM * f);
+        if (ds < HM) return fail(h, VNECT_E_ARG, "scale > 1 not supported");
+        MergeTab& m = mt.t[i];
+        m.copy = ds == HM;
+        const double scale = 1.0 / f;
+        AxisTab x = axis_x(HM, ds, scale), y = axis_y(HM, ds, scale);
+        const int off = ds / 2 - HM / 2;
+        for (int r = 0; r < HM; r++) {
+            const int d = r + off;
+            m.sx[r] = x.s0[d], m.edge[r] = x.edge[d];
+            m.a0[r] = 1.f - x.f[d], m.a1[r] = x.f[d];
+            m.sy0[r] = y.s0[d], m.sy1[r] = y.s1[d];
+            m.b0[r] = 1.f - y.f[d], m.b1[r] = y.f[d];
+        }
+    }
+    HIPCK(h, hipMemcpy(h->d_stabs, &st, sizeof st, hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->d_mtabs, &mt, sizeof mt, hipMemcpyHostToDevice));
+    return VNECT_OK;
+}
+
+int build_up_table(vnect_handle* h)
+{
+    // utils.py:169-171: cv2.resize(hm (46,46) f64, fx=fy=8) -> 368x368
+    std::vector<UpTab> u(1);
+    AxisTab x = axis_x(HM, BOX, 1.0 / 8.0), y = axis_y(HM, BOX, 1.0 / 8.0);
+    for (int d = 0; d < BOX; d++) {
+        u[0].sx[d] = x.s0[d], u[0].edge[d] = x.edge[d];
+        u[0].a0[d] = (double)(1.f - x.f[d]), u[0].a1[d] = (double)x.f[d];
+        u[0].sy0[d] = y.s0[d], u[0].sy1[d] = y.s1[d];
+        u[0].b0[d] = (double)(1.f - y.f[d]), u[0].b1[d] = (double)y.f[d];
+    }
+    HIPCK(h, hipMemcpy(h->d_up, u.data(), sizeof(UpTab), hipMemcpyHostToDevice));
+    return VNECT_OK;
+}
+
+// utils.img_scale_squarify + img_padding geometry for an (H,W) frame
+int squarify_params(vnect_handle* h, int H, int W, FrameParams* fp)
+{
+    if (H < 1 || W < 1 || H > 8192 || W > 8192) return fail(h, VNECT_E_ARG, "frame size out of range");
+    if (h->sq_H != H || h->sq_W != W) {
+        FrameParams c;
+        memset(&c, 0, sizeof c);
+        c.scaler = (double)BOX / std::max(H, W);
+        if (!build_u8_tab(H, W, c.scaler, &c.sq)) return fail(h, VNECT_E_ARG, "squarify: scaled size exceeds 368");
+        const int h2 = c.sq.dh, w2 = c.sq.dw;
+        // utils.py:98-103 indexes a 368-long axis with the scaled long side; numpy raises if it is not 368
+        if ((h2 > w2 ? h2 : w2) != BOX) return fail(h, VNECT_E_ARG, "squarify: scaled long side != 368");
+        if (h2 > w2) c.offx = BOX / 2 - w2 / 2;
+        else c.offy = BOX / 2 - h2 / 2;
+        c.H = H, c.W = W;
+        h->sq_cache = c, h->sq_H = H, h->sq_W = W;
+    }
+    *fp = h->sq_cache;
+    return VNECT_OK;
+}
+
+// ---- network construction --------------------------------------------------------------------------
+int add_tensor(vnect_handle* h, const std::string& name, int S, int H, int W, int C, int Cs)
+{
+    Tensor t;
+    t.name = name, t.S = S, t.H = H, t.W = W, t.C = C, t.Cs = Cs;
+    h->tensors.push_back(t);
+    h->tensor_by_name[name] = (int)h->tensors.size() - 1;
+    return (int)h->tensors.size() - 1;
+}
+
+const HostArray* get_w(vnect_handle* h, const std::string& name, std::vector<int64_t> shape)
+{
+    auto it = h->weights.find(name);
+    if (it == h->weights.end()) {
+        h->err = "missing weight array " + name;
+        return nullptr;
+    }
+    if (it->second.shape != shape) {
+        h->err = "weight " + name + " has the wrong shape";
+        return nullptr;
+    }
+    return &it->second;
+}
+
+void same_pad(int in, int k, int stride, int* out, int* before)
+{
+    *out = (in + stride - 1) / stride;
+    int tot = std::max((*out - 1) * stride + k - in, 0);
+    *before = tot / 2;
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// cycles model used to pick the tile and the K split of a layer (tuned against rocprof)
+void choose_tile(Layer& L, long long npix)
+{
+    static const int cfgs[4][2] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}};
+    const int nch = L.a.ntaps * L.a.cpt;
+    double best = 1e30;
+    int bBM = 64, bBN = 64, bks = 1;
+    const char* force = getenv("VNECT_FORCE_TILE");  // "BM,BN,ks" for experiments
+    int fBM = 0, fBN = 0, fks = 0;
+    if (force) sscanf(force, "%d,%d,%d", &fBM, &fBN, &fks);
+    for (auto& c : cfgs) {
+        const int BM = c[0], BN = c[1];
+        if (fBM && (BM != fBM || BN != fBN)) continue;
+        const int Npad = round_up(L.Nreal, BN);
+        const long long tiles = (long long)((L.a.M + BM - 1) / BM) * (Npad / BN) * L.a.nphase;
+        for (int ks = 1; ks <= std::min(8, nch); ks++) {
+            if (fks && ks != fks) continue;
+            const long long wgs = tiles * ks;
+            const double rounds = ceil((double)wgs / 256.0);
+            const double per_chunk = (BM / 64) * (BN / 64) * 1024.0 + 350.0;
+            double t = rounds * ceil((double)nch / ks) * per_chunk + 2500.0;
+            if (ks > 1) t += (double)(ks + 1) * npix * Npad * 4.0 / 900.0 + 5000.0;
+            if (t < best) best = t, bBM = BM, bBN = BN, bks = ks;
+        }
+    }
+    L.BM = bBM, L.BN = bBN, L.a.ksplit = bks;
+}
+
+struct ConvSpec {
+    std::string scope, out_name;
+    int in = -1, resid = -1;
+    int k = 1, stride = 1, cout = 0;
+    bool relu = false;
+};
+
+// tc.layers.conv2d scope -> Layer (weights HWIO + bias); returns the output tensor index or -1
+int add_conv(vnect_handle* h, const ConvSpec& sp)
+{
+    const Tensor tin = h->tensors[sp.in];
+    const bool conv1 = sp.k == 7;
+    const int cin = tin.C;
+    const HostArray* W = get_w(h, sp.scope + "/weights", {sp.k, sp.k, cin, sp.cout});
+    const HostArray* B = W ? get_w(h, sp.scope + "/biases", {sp.cout}) : nullptr;
+    if (!W || !B) return -1;
+    int ho, wo, pt = 0, pl = 0;
+    if (sp.k == 1) ho = (tin.H - 1) / sp.stride + 1, wo = (tin.W - 1) / sp.stride + 1;  // VALID
+    else same_pad(tin.H, sp.k, sp.stride, &ho, &pt), same_pad(tin.W, sp.k, sp.stride, &wo, &pl);
+    Layer L;
+    L.op = OP_CONV, L.name = sp.scope, L.in = sp.in, L.resid = sp.resid;
+    L.out = add_tensor(h, sp.out_name, tin.S, ho, wo, sp.cout, sp.cout);
+    ConvArgs& a = L.a;
+    a.S = tin.S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
+    a.Ho = ho, a.Wo = wo, a.M = tin.S * ho * wo;
+    a.stride = sp.stride;
+    a.OH = ho, a.OW = wo, a.os = 1, a.nphase = 1;
+    a.ldc = sp.cout, a.ldr = sp.cout;
+    a.relu_cols = sp.relu ? sp.cout : 0;
+    a.Nvalid = sp.cout;
+    L.Nreal = sp.cout;
+    int cp;  // channels per tap in the packed K
+    if (conv1) {
+        // K = 7 rows x (8 pixels x 4 channels): pixel 7 and channel 3 carry zero weights
+        a.pixmode = 1, a.ntaps = 7, a.cpt = 1, cp = 32;
+        for (int ky = 0; ky < 7; ky++) a.dy[ky] = (int8_t)(ky - pt), a.dx[ky] = (int8_t)(-pl);
+    } else {
+        cp = round_up(tin.Cs, 32);
+        if (cp != tin.Cs) {
+            h->err = "internal: input channel stride not a multiple of 32 at " + sp.scope;
+            return -1;
+        }
+        a.pixmode = 0, a.ntaps = sp.k * sp.k, a.cpt = cp / 32;
+        for (int ky = 0; ky < sp.k; ky++)
+            for (int kx = 0; kx < sp.k; kx++) a.dy[ky * sp.k + kx] = (int8_t)(ky - pt), a.dx[ky * sp.k + kx] = (int8_t)(kx - pl);
+    }
+    a.K = a.ntaps * a.cpt * 32;
+    L.Kreal = sp.k * sp.k * cin;
+    L.flops = 2.0 * a.M * (double)L.Kreal * sp.cout;
+    choose_tile(L, (long long)a.M);
+    a.Npad = round_up(sp.cout, L.BN);
+    std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
+    for (int ky = 0; ky < sp.k; ky++)
+        for (int kx = 0; kx < sp.k; kx++)
+            for (int ci = 0; ci < cin; ci++) {
+                const float* src = &W->d[(((size_t)ky * sp.k + kx) * cin + ci) * sp.cout];
+                const size_t kidx = conv1 ? (size_t)ky * 32 + kx * 4 + ci : (size_t)(ky * sp.k + kx) * cp + ci;
+                for (int n = 0; n < sp.cout; n++) wp[(size_t)n * a.K + kidx] = src[n];
+            }
+    for (int n = 0; n < sp.cout; n++) bp[n] = B->d[n];
+    if (upload(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
+    h->layers.push_back(L);
+    return L.out;
+}
+
+int finalize_impl(vnect_handle* h)
+{
+    const int S = h->S;
+    h->tensors.clear(), h->layers.clear(), h->tensor_by_name.clear();
+    h->t_input4 = add_tensor(h, "input", S, BOX, BOX, 3, 4);
+    auto conv = [&](const std::string& scope, int in, int k, int stride, int cout, bool relu, int resid = -1,
+                    const std::string& out_name = "") {
+        ConvSpec sp;
+        sp.scope = scope, sp.out_name = out_name.empty() ? scope : out_name;
+        sp.in = in, sp.resid = resid, sp.k = k, sp.stride = stride, sp.cout = cout, sp.relu = relu;
+        return add_conv(h, sp);
+    };
+#define NEED(x)                                 \
+    do {                                        \
+        if ((x) < 0) return VNECT_E_ARG;        \
+    } while (0)
+    // vnect_model.py:27-29
+    int conv1 = conv("conv1", h->t_input4, 7, 2, 64, true);
+    NEED(conv1);
+    int pool1;
+    {
+        const Tensor t = h->tensors[conv1];
+        int ho, wo, p;
+        same_pad(t.H, 3, 2, &ho, &p), same_pad(t.W, 3, 2, &wo, &p);
+        Layer L;
+        L.op = OP_POOL, L.name = "pool1", L.in = conv1;
+        pool1 = L.out = add_tensor(h, "pool1", S, ho, wo, 64, 64);
+        h->layers.push_back(L);
+    }
+    // bottleneck blocks (vnect_model.py:31-165); block output tensors are named resNx
+    auto proj = [&](const std::string& p, int x, int mid, int out, int stride) {
+        int s = conv(p + "_branch1", x, 1, stride, out, false);
+        int a = s < 0 ? -1 : conv(p + "_branch2a", x, 1, stride, mid, true);
+        int b = a < 0 ? -1 : conv(p + "_branch2b", a, 3, 1, mid, true);
+        return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, s, p);
+    };
+    auto ident = [&](const std::string& p, int x, int mid, int out, int* branch2a = nullptr) {
+        int a = conv(p + "_branch2a", x, 1, 1, mid, true);
+        if (branch2a) *branch2a = a;
+        int b = a < 0 ? -1 : conv(p + "_branch2b", a, 3, 1, mid, true);
+        return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, x, p);
+    };
+    int r = proj("res2a", pool1, 64, 256, 1);
+    NEED(r);
+    int r2b_2a = -1;
+    int r2b = ident("res2b", r, 64, 256, &r2b_2a);
+    NEED(r2b);
+    {
+        // vnect_model.py:54-57: res2c_branch2b consumes res2b_branch2a; res2c_branch2a is dead and pruned
+        int a = r2b_2a;
+        if (h->cfg.paper_res2c) {
+            a = conv("res2c_branch2a", r2b, 1, 1, 64, true);
+            NEED(a);
+        } else if (!get_w(h, "res2c_branch2a/weights", {1, 1, 256, 64})) {
+            return VNECT_E_ARG;  // schema completeness, like the reference's load_weights
+        }
+        int b = conv("res2c_branch2b", a, 3, 1, 64, true);
+        NEED(b);
+        r = conv("res2c_branch2c", b, 1, 1, 256, true, r2b, "res2c");
+        NEED(r);
+    }
+    r = proj("res3a", r, 128, 512, 2);
+    NEED(r);
+    for (const char* p : {"res3b", "res3c", "res3d"}) {
+        r = ident(p, r, 128, 512);
+        NEED(r);
+    }
+    r = proj("res4a", r, 256, 1024, 2);
+    NEED(r);
+    for (const char* p : {"res4b", "res4c", "res4d", "res4e", "res4f"}) {
+        r = ident(p, r, 256, 1024);
+        NEED(r);
+    }
+    // res5a / res5b (vnect_model.py:167-185)
+    {
+        int a = conv("res5a_branch2a_new", r, 1, 1, 512, true);
+        NEED(a);
+        int b = conv("res5a_branch2b_new", a, 3, 1, 512, true);
+        NEED(b);
+        int s = conv("res5a_branch1_new", r, 1, 1, 1024, false);
+        NEED(s);
+        r = conv("res5a_branch2c_new", b, 1, 1, 1024, true, s, "res5a");
+        NEED(r);
+        a = conv("res5b_branch2a_new", r, 1, 1, 256, true);
+        NEED(a);
+        b = conv("res5b_branch2b_new", a, 3, 1, 128, true);
+        NEED(b);
+        r = conv("res5b_branch2c_new", b, 1, 1, 256, true);
+        NEED(r);
+    }
+    // Transposed convs + BN + ReLU + deltas, one 4-phase launch (vnect_model.py:188-209).
+    // out[2i-1+ky, 2j-1+kx, oc] += in[i,j,ic] * W[ky,kx,oc,ic]; phase (py,px) = (oy&1, ox&1):
+    //   py = 0: ky = 1 reads row i', ky = 3 reads row i'-1;  py = 1: ky = 0 reads row i'+1, ky = 2 reads row i'.
+    int feat;
+    {
+        const Tensor tin = h->tensors[r];
+        const HostArray* W1 = get_w(h, "res5c_branch1a/kernel", {4, 4, 63, 256});
+        const HostArray* W2 = get_w(h, "res5c_branch2a/kernel", {4, 4, 128, 256});
+        const HostArray* ga = get_w(h, "bn5c_branch2a/gamma", {128});
+        const HostArray* be = get_w(h, "bn5c_branch2a/beta", {128});
+        const HostArray* mu = get_w(h, "bn5c_branch2a/moving_mean", {128});
+        const HostArray* va = get_w(h, "bn5c_branch2a/moving_variance", {128});
+        if (!W1 || !W2 || !ga || !be || !mu || !va) return VNECT_E_ARG;
+        Layer L;
+        L.op = OP_CONV, L.name = "res5c_deconv", L.in = r;
+        feat = L.out = add_tensor(h, "res5c_branch2a_feat", S, 2 * tin.H, 2 * tin.W, 212, 224);
+        ConvArgs& a = L.a;
+        a.S = S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
+        a.Ho = tin.H, a.Wo = tin.W, a.M = S * tin.H * tin.W;
+        a.stride = 1, a.OH = 2 * tin.H, a.OW = 2 * tin.W, a.os = 2, a.nphase = 4;
+        a.ntaps = 4, a.cpt = tin.Cs / 32, a.K = 4 * tin.Cs;
+        a.ldc = 224, a.ldr = 0, a.relu_cols = 128, a.Nvalid = 191;
+        L.Nreal = 191, L.Kreal = 4 * 256;
+        L.flops = 2.0 * (double)S * 46 * 46 * 4 * 256 * 191;
+        choose_tile(L, (long long)S * 46 * 46);
+        a.Npad = round_up(191, L.BN);
+        a.w_phase_stride = (long long)a.Npad * a.K;
+        const int kys[2][2] = {{1, 3}, {0, 2}}, dys[2][2] = {{0, -1}, {1, 0}};
+        std::vector<float> wp((size_t)4 * a.Npad * a.K, 0.f);
+        for (int py = 0; py < 2; py++)
+            for (int px = 0; px < 2; px++) {
+                const int z = py * 2 + px;
+                for (int ta = 0; ta < 2; ta++)
+                    for (int tb = 0; tb < 2; tb++) {
+                        const int t = ta * 2 + tb, ky = kys[py][ta], kx = kys[px][tb];
+                        a.dy[z * 4 + t] = (int8_t)dys[py][ta], a.dx[z * 4 + t] = (int8_t)dys[px][tb];
+                        for (int n = 0; n < 191; n++) {
+                            const float* src = n < 128 ? &W2->d[(((size_t)ky * 4 + kx) * 128 + n) * 256]
+                                                       : &W1->d[(((size_t)ky * 4 + kx) * 63 + (n - 128)) * 256];
+                            float* dst = &wp[((size_t)z * a.Npad + n) * a.K + (size_t)t * 256];
+                            memcpy(dst, src, 256 * sizeof(float));
+                        }
+                    }
+            }
+        // FusedBatchNorm inference (contrib batch_norm default epsilon 0.001): (x - mean) * (gamma * rsqrt(var + eps)) + beta
+        std::vector<float> bp(a.Npad, 0.f), sc(a.Npad, 1.f), sh(a.Npad, 0.f);
+        for (int c = 0; c < 128; c++) {
+            bp[c] = -mu->d[c];
+            sc[c] = ga->d[c] * (1.0f / sqrtf(va->d[c] + 0.001f));
+            sh[c] = be->d[c];
+        }
+        if (upload(h, &L.w, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
+            return VNECT_E_HIP;
+        h->layers.push_back(L);
+        Layer Bn;
+        Bn.op = OP_BONE, Bn.name = "res5c_bone_length", Bn.in = feat, Bn.out = feat;
+        h->layers.push_back(Bn);
+    }
+    // head (vnect_model.py:211-217)
+    int hd = conv("res5c_branch2b", feat, 3, 1, 128, true);
+    NEED(hd);
+    {
+        const HostArray* Wk = get_w(h, "res5c_branch2c/kernel", {1, 1, 128, 84});
+        if (!Wk) return VNECT_E_ARG;
+        // tf.layers.conv2d without bias == the tc.layers form with zero biases
+        HostArray z;
+        z.d.assign(84, 0.f), z.shape = {84};
+        h->weights["res5c_branch2c/weights"] = *Wk;
+        h->weights["res5c_branch2c/biases"] = z;
+        h->t_out = conv("res5c_branch2c", hd, 1, 1, 84, false);
+        h->weights.erase("res5c_branch2c/weights"), h->weights.erase("res5c_branch2c/biases");
+        NEED(h->t_out);
+    }
+#undef NEED
+    // buffers
+    for (Tensor& t : h->tensors) {
+        int rc = dev_alloc(h, &t.d, t.floats());
+        if (rc) return rc;
+        HIPCK(h, hipMemset(t.d, 0, t.floats() * sizeof(float)));
+    }
+    size_t ws = 0;
+    for (Layer& L : h->layers)
+        if (L.op == OP_CONV && L.a.ksplit > 1)
+            ws = std::max(ws, (size_t)L.a.ksplit * L.a.S * L.a.OH * L.a.OW * L.a.Npad);
+    h->ws_floats = ws;
+    if (ws) {
+        int rc = dev_alloc(h, &h->ws, ws);
+        if (rc) return rc;
+    }
+    HIPCK(h, hipDeviceSynchronize());
+    h->conv_flops = 0, h->conv_launches = 0;
+    for (Layer& L : h->layers) {
+        if (L.op != OP_CONV) continue;
+        ConvArgs& a = L.a;
+        a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
+        a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
+        a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws;
+        if (a.ksplit > 1) {
+            ReduceArgs& q = L.r;
+            q.ws = h->ws, q.bias = L.bias, q.scale = L.scale, q.shift = L.shift, q.resid = a.resid, q.out = a.out;
+            q.npix = (long long)a.S * a.OH * a.OW, q.Npad = a.Npad, q.Nvalid = a.Nvalid, q.ldc = a.ldc, q.ldr = a.ldr;
+            q.ksplit = a.ksplit, q.relu_cols = a.relu_cols;
+        }
+        h->conv_flops += L.flops;
+        h->conv_launches += 1;
+    }
+    return VNECT_OK;
+}
+
+// ---- launch sequences -------------------------------------------------------------------------------
+int run_network(vnect_handle* h, bool timed)
+{
+    for (Layer& L : h->layers) {
+        if (timed) {
+            if (!L.e0) HIPCK(h, hipEventCreate(&L.e0));
+            if (!L.e1) HIPCK(h, hipEventCreate(&L.e1));
+            HIPCK(h, hipEventRecord(L.e0, h->st));
+        }
+        if (L.op == OP_CONV) {
+            HIPCK(h, launch_conv(L.a, L.BM, L.BN, h->st));
+            if (L.a.ksplit > 1) HIPCK(h, launch_reduce(L.r, h->st));
+        } else if (L.op == OP_POOL) {
+            const Tensor &i = h->tensors[L.in], &o = h->tensors[L.out];
+            HIPCK(h, launch_maxpool(i.d, o.d, i.S, i.H, i.W, i.Cs, o.H, o.W, h->st));
+        } else {
+            const Tensor& t = h->tensors[L.out];
+            HIPCK(h, launch_bone(t.d, (long long)t.S * t.H * t.W, t.Cs, h->st));
+        }
+        if (timed) HIPCK(h, hipEventRecord(L.e1, h->st));
+    }
+    return VNECT_OK;
+}
+
+int run_pre(vnect_handle* h)
+{
+    HIPCK(h, launch_squarify(h->d_fp, h->sq, h->st));
+    HIPCK(h, launch_pyramid(h->sq, h->d_stabs, h->tensors[h->t_input4].d, h->S, h->st));
+    return VNECT_OK;
+}
+
+int run_post(vnect_handle* h)
+{
+    HIPCK(h, launch_merge(h->tensors[h->t_out].d, h->d_mtabs, h->d_avg, h->S, h->st));
+    HIPCK(h, launch_argmax(h->d_avg, h->d_up, h->d_part, h->st));
+    HIPCK(h, launch_joints(h->d_part, h->d_avg, h->d_fb, h->d_fp, h->cfg.numpy_promotion, h->d_out, h->st));
+    return VNECT_OK;
+}
+
+int check_time(vnect_handle* h, double t2d, double t3d)
+{
+    // OneEuroFilter.py:65-66: freq = 1/(t - lasttime) when both are truthy -> ZeroDivisionError on equal stamps
+    if (h->have2 && h->last2 != 0.0 && t2d != 0.0 && t2d == h->last2)
+        return fail(h, VNECT_E_TIMESTAMP, "t2d equals the previous 2-D filter timestamp");
+    if (h->have3 && h->last3 != 0.0 && t3d != 0.0 && t3d == h->last3)
+        return fail(h, VNECT_E_TIMESTAMP, "t3d equals the previous 3-D filter timestamp");
+    h->have2 = h->have3 = true, h->last2 = t2d, h->last3 = t3d;
+    return VNECT_OK;
+}
+
+int reset_filters_impl(vnect_handle* h)
+{
+    std::vector<FilterBank> fb(1);
+    memset(fb.data(), 0, sizeof(FilterBank));
+    for (int j = 0; j < NJ; j++) {
+        for (int k = 0; k < 2; k++) {  // filter_config_2d, estimator.py:34-39
+            Filt& f = fb[0].f2[j][k];
+            f.freq = 30, f.mincutoff = 1.7, f.beta = 0.3, f.dcutoff = 0.4;
+        }
+        for (int k = 0; k < 3; k++) {  // filter_config_3d, estimator.py:40-45
+            Filt& f = fb[0].f3[j][k];
+            f.freq = 30, f.mincutoff = 0.8, f.beta = 0.4, f.dcutoff = 0.4;
+        }
+    }
+    HIPCK(h, hipMemcpyAsync(h->d_fb, fb.data(), sizeof(FilterBank), hipMemcpyHostToDevice, h->st));
+    HIPCK(h, hipStreamSynchronize(h->st));
+    h->have2 = h->have3 = false;
+    return VNECT_OK;
+}
+
+int build_graph(vnect_handle* h)
+{
+    if (h->gexec) {
+        hipGraphExecDestroy(h->gexec), h->gexec = nullptr;
+        hipGraphDestroy(h->graph), h->graph = nullptr;
+    }
+    if (!h->cfg.use_graph) return VNECT_OK;
+    HIPCK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+    int rc = run_pre(h);
+    if (!rc) rc = run_network(h, false);
+    if (!rc) rc = run_post(h);
+    hipError_t e = hipStreamEndCapture(h->st, &h->graph);
+    if (rc) return rc;
+    HIPCK(h, e);
+    HIPCK(h, hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+    return VNECT_OK;
+}
+
+// enqueue one frame from a resident slot; results land in h_out[ring]
+int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_out)
+{
+    if (slot < 0 || slot >= (int)h->slots.size() || h->slots[slot].H == 0)
+        return fail(h, VNECT_E_ARG, "frame slot empty or out of range");
+    if (h->seq_submit - h->seq_collect >= 2) return fail(h, VNECT_E_STATE, "two frames already in flight");
+    const auto& si = h->slots[slot];
+    FrameParams fp;
+    int rc = squarify_params(h, si.H, si.W, &fp);
+    if (rc) return rc;
+    rc = check_time(h, t2d, t3d);
+    if (rc) return rc;
+    const int ring = (int)(h->seq_submit % RING);
+    fp.t2d = t2d, fp.t3d = t3d;
+    fp.row_stride = si.stride;
+    fp.frame = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
+    *h->h_fp[ring] = fp;
+    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[ring], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
+    const bool timed = h->profiling;
+    if (h->gexec && !timed) {
+        HIPCK(h, hipGraphLaunch(h->gexec, h->st));
+    } else {
+        if (timed) HIPCK(h, hipEventRecord(h->ev[0], h->st));
+        rc = run_pre(h);
+        if (rc) return rc;
+        if (timed) HIPCK(h, hipEventRecord(h->ev[1], h->st));
+        rc = run_network(h, timed);
+        if (rc) return rc;
+        if (timed) HIPCK(h, hipEventRecord(h->ev[2], h->st));
+        rc = run_post(h);
+        if (rc) return rc;
+        if (timed) HIPCK(h, hipEventRecord(h->ev[3], h->st));
+    }
+    HIPCK(h, hipMemcpyAsync(h->h_out[ring], h->d_out, sizeof(JointsOut), hipMemcpyDeviceToHost, h->st));
+    HIPCK(h, hipEventRecord(h->done[ring], h->st));
+    h->seq_submit++;
+    *ring_out = ring;
+    return VNECT_OK;
+}
+
+int collect_impl(vnect_handle* h, double* j2, float* j3)
+{
+    if (h->seq_collect == h->seq_submit) return fail(h, VNECT_E_STATE, "nothing in flight");
+    const int ring = (int)(h->seq_collect % RING);
+    HIPCK(h, hipEventSynchronize(h->done[ring]));
+    h->seq_collect++;
+    if (j2) memcpy(j2, h->h_out[ring]->j2d, sizeof(double) * NJ * 2);
+    if (j3) memcpy(j3, h->h_out[ring]->j3d, sizeof(float) * NJ * 3);
+    if (h->profiling) {
+        float a = 0, b = 0, c = 0;
+        hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+        hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
+        hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
+        h->tim.frames++, h->tim.pre_ms += a, h->tim.net_ms += b, h->tim.post_ms += c, h->tim.total_ms += a + b + c;
+        for (Layer& L : h->layers)
+            if (L.e0 && L.e1) hipEventElapsedTime(&L.last_ms, L.e0, L.e1);
+    }
+    return VNECT_OK;
+}
+
+int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
+{
+    if (!bgr || slot < 0 || slot >= (int)h->slots.size()) return fail(h, VNECT_E_ARG, "bad frame slot");
+    if (H < 1 || W < 1 || row_stride < (int64_t)W * 3) return fail(h, VNECT_E_ARG, "bad frame geometry");
+    if ((size_t)H * W * 3 > (size_t)h->cfg.max_frame_bytes) return fail(h, VNECT_E_ARG, "frame larger than max_frame_bytes");
+    uint8_t* dst = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
+    // a frame still being read by an in-flight inference must not be overwritten
+    HIPCK(h, hipStreamSynchronize(h->st));
+    HIPCK(h, hipMemcpy2D(dst, (size_t)W * 3, bgr, (size_t)row_stride, (size_t)W * 3, H, hipMemcpyHostToDevice));
+    h->slots[slot].H = H, h->slots[slot].W = W, h->slots[slot].stride = (long long)W * 3;
+    return VNECT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int vnect_abi_version(void) { return VNECT_ABI_VERSION; }
+
+const char* vnect_last_error(vnect_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int vnect_create(const vnect_config* cfg, vnect_handle** out)
+{
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(vnect_config))
+        return fail(nullptr, VNECT_E_ARG, "vnect_create: bad config (struct_size mismatch)");
+    if (cfg->num_scales < 1 || cfg->num_scales > VNECT_MAX_SCALES)
+        return fail(nullptr, VNECT_E_ARG, "vnect_create: num_scales out of range");
+    if (cfg->precision != VNECT_FP32)
+        return fail(nullptr, VNECT_E_ARG, "vnect_create: only VNECT_FP32 is built in this round");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: no HIP device " + std::to_string(cfg->device));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || !strstr(prop.gcnArchName, "gfx950"))
+        return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: device is not gfx950 (MI355X); kernels are built for gfx950 only");
+    vnect_handle* h = new vnect_handle();
+    h->cfg = *cfg;
+    h->S = cfg->num_scales;
+    if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
+    if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
+    *out = h;  // returned even on failure below so the caller can read the message, then destroy
+    HIPCK(h, hipSetDevice(cfg->device));
+    HIPCK(h, hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    HIPCK(h, conv_setup());
+    h->slots.resize(h->cfg.num_frame_slots);
+    int rc;
+    if ((rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
+    if ((rc = dev_alloc(h, &h->sq, (size_t)BOX * BOX * 3))) return rc;
+    if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_avg, (size_t)4 * HM * HM * NJ))) return rc;
+    if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
+    if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_out, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
+    for (int i = 0; i < RING; i++) {
+        HIPCK(h, hipHostMalloc((void**)&h->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
+        HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocDefault));
+        HIPCK(h, hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming));
+    }
+    for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
+    if ((rc = build_scale_tables(h))) return rc;
+    if ((rc = build_up_table(h))) return rc;
+    if ((rc = reset_filters_impl(h))) return rc;
+    h->tim.struct_size = sizeof(vnect_timings);
+    return VNECT_OK;
+}
+
+void vnect_destroy(vnect_handle* h)
+{
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->st) hipStreamSynchronize(h->st);
+    if (h->gexec) hipGraphExecDestroy(h->gexec);
+    if (h->graph) hipGraphDestroy(h->graph);
+    for (Layer& L : h->layers) {
+        if (L.e0) hipEventDestroy(L.e0);
+        if (L.e1) hipEventDestroy(L.e1);
+    }
+    for (int i = 0; i < RING; i++) {
+        if (h->h_fp[i]) hipHostFree(h->h_fp[i]);
+        if (h->h_out[i]) hipHostFree(h->h_out[i]);
+        if (h->done[i]) hipEventDestroy(h->done[i]);
+    }
+    for (auto& e : h->ev)
+        if (e) hipEventDestroy(e);
+    for (void* p : h->dev_allocs) hipFree(p);
+    if (h->st) hipStreamDestroy(h->st);
+    delete h;
+}
+
+int vnect_set_weight(vnect_handle* h, const char* name, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h) return VNECT_E_ARG;
+    if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(h, VNECT_E_ARG, "vnect_set_weight: bad argument");
+    if (h->finalized) return fail(h, VNECT_E_STATE, "vnect_set_weight after vnect_finalize");
+    HostArray a;
+    size_t n = 1;
+    for (int i = 0; i < ndim; i++) {
+        if (shape[i] < 1) return fail(h, VNECT_E_ARG, "vnect_set_weight: bad shape");
+        a.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    a.d.assign(data, data + n);
+    h->weights[name] = std::move(a);
+    return VNECT_OK;
+}
+
+int vnect_finalize(vnect_handle* h)
+{
+    if (!h) return VNECT_E_ARG;
+    if (h->finalized) return fail(h, VNECT_E_STATE, "already finalized");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = finalize_impl(h);
+    if (rc) {
+        if (h->err.empty()) h->err = "finalize failed";
+        return rc;
+    }
+    rc = build_graph(h);
+    if (rc) return rc;
+    HIPCK(h, hipStreamSynchronize(h->st));
+    h->finalized = true;
+    h->weights.clear();
+    return VNECT_OK;
+}
+
+int vnect_set_scales(vnect_handle* h, const double* scales, int n)
+{
+    if (!h || !scales) return VNECT_E_ARG;
+    if (n != h->S) return fail(h, VNECT_E_ARG, "vnect_set_scales: the number of scales is fixed at create time");
+    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    HIPCK(h, hipStreamSynchronize(h->st));
+    double old[VNECT_MAX_SCALES];
+    memcpy(old, h->cfg.scales, sizeof old);
+    for (int i = 0; i < n; i++) h->cfg.scales[i] = scales[i];
+    int rc = build_scale_tables(h);
+    if (rc) {
+        memcpy(h->cfg.scales, old, sizeof old);
+        build_scale_tables(h);
+    }
+    return rc;
+}
+
+int vnect_forward(vnect_handle* h, const float* batch, int num_images, float* out)
+{
+    if (!h || !batch || !out) return VNECT_E_ARG;
+    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_forward before vnect_finalize");
+    if (num_images != h->S) return fail(h, VNECT_E_ARG, "vnect_forward: num_images must equal num_scales");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    const long long npix = (long long)h->S * BOX * BOX;
+    HIPCK(h, hipMemcpyAsync(h->in3, batch, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->st));
+    HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->st));
+    int rc = run_network(h, h->profiling);
+    if (rc) return rc;
+    const Tensor& t = h->tensors[h->t_out];
+    HIPCK(h, hipMemcpyAsync(out, t.d, t.floats() * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    HIPCK(h, hipStreamSynchronize(h->st));
+    if (h->profiling)
+        for (Layer& L : h->layers)
+            if (L.e0 && L.e1) hipEventElapsedTime(&L.last_ms, L.e0, L.e1);
+    return VNECT_OK;
+}
+
+int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, float* batch_out,
+                     double* scaler, int32_t* offset_x, int32_t* offset_y)
+{
+    if (!h || !bgr) return VNECT_E_ARG;
+    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_preprocess before vnect_finalize");
+    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
+    if (rc) return rc;
+    FrameParams fp;
+    if ((rc = squarify_params(h, H, W, &fp))) return rc;
+    fp.row_stride = h->slots[0].stride, fp.frame = h->frames;
+    *h->h_fp[0] = fp;
+    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[0], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
+    if ((rc = run_pre(h))) return rc;
+    if (batch_out) {
+        const long long npix = (long long)h->S * BOX * BOX;
+        HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->st));
+        HIPCK(h, hipMemcpyAsync(batch_out, h->in3, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    }
+    HIPCK(h, hipStreamSynchronize(h->st));
+    if (scaler) *scaler = fp.scaler;
+    if (offset_x) *offset_x = fp.offx;
+    if (offset_y) *offset_y = fp.offy;
+    return VNECT_OK;
+}
+
+int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d, double scaler, int32_t offset_x,
+                      int32_t offset_y, double* j2, float* j3)
+{
+    if (!h || !maps || !j2 || !j3) return VNECT_E_ARG;
+    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_postprocess before vnect_finalize");
+    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+    if (!(scaler > 0)) return fail(h, VNECT_E_ARG, "scaler must be positive");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = check_time(h, t2d, t3d);
+    if (rc) return rc;
+    const Tensor& t = h->tensors[h->t_out];
+    HIPCK(h, hipMemcpyAsync(t.d, maps, t.floats() * sizeof(float), hipMemcpyHostToDevice, h->st));
+    FrameParams fp;
+    memset(&fp, 0, sizeof fp);
+    fp.t2d = t2d, fp.t3d = t3d, fp.scaler = scaler, fp.offx = offset_x, fp.offy = offset_y;
+    *h->h_fp[0] = fp;
+    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[0], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
+    if ((rc = run_post(h))) return rc;
+    HIPCK(h, hipMemcpyAsync(h->h_out[0], h->d_out, sizeof(JointsOut), hipMemcpyDeviceToHost, h->st));
+    HIPCK(h, hipStreamSynchronize(h->st));
+    memcpy(j2, h->h_out[0]->j2d, sizeof(double) * NJ * 2);
+    memcpy(j3, h->h_out[0]->j3d, sizeof(float) * NJ * 3);
+    return VNECT_OK;
+}
+
+int vnect_upload_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
+{
+    if (!h) return VNECT_E_ARG;
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    return upload_frame_impl(h, slot, bgr, H, W, row_stride);
+}
+
+int vnect_submit_resident(vnect_handle* h, int slot, double t2d, double t3d)
+{
+    if (!h) return VNECT_E_ARG;
+    if (!h->finalized) return fail(h, VNECT_E_STATE, "inference before vnect_finalize");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int ring;
+    return enqueue_frame(h, slot, t2d, t3d, &ring);
+}
+
+int vnect_collect(vnect_handle* h, double* j2, float* j3)
+{
+    if (!h) return VNECT_E_ARG;
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    return collect_impl(h, j2, j3);
+}
+
+int vnect_infer_resident(vnect_handle* h, int slot, double t2d, double t3d, double* j2, float* j3)
+{
+    if (!h || !j2 || !j3) return VNECT_E_ARG;
+    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+    int rc = vnect_submit_resident(h, slot, t2d, t3d);
+    if (rc) return rc;
+    return collect_impl(h, j2, j3);
+}
+
+int vnect_infer(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, double t2d, double t3d,
+                double* j2, float* j3)
+{
+    if (!h || !bgr || !j2 || !j3) return VNECT_E_ARG;
+    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_infer before vnect_finalize");
+    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
+    if (rc) return rc;
+    return vnect_infer_resident(h, 0, t2d, t3d, j2, j3);
+}
+
+int vnect_reset_filters(vnect_handle* h)
+{
+    if (!h) return VNECT_E_ARG;
+    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    return reset_filters_impl(h);
+}
+
+int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t capacity, int32_t* shape4)
+{
+    if (!h || !name || !shape4) return VNECT_E_ARG;
+    if (!h->finalized) return fail(h, VNECT_E_STATE, "not finalized");
+    auto it = h->tensor_by_name.find(name);
+    if (it == h->tensor_by_name.end()) return fail(h, VNECT_E_ARG, std::string("no activation named ") + name);
+    const Tensor& t = h->tensors[it->second];
+    shape4[0] = t.S, shape4[1] = t.H, shape4[2] = t.W, shape4[3] = t.C;
+    if (!out) return VNECT_OK;
+    const size_t npix = (size_t)t.S * t.H * t.W;
+    if ((int64_t)(npix * t.C) > capacity) return fail(h, VNECT_E_ARG, "vnect_read_activation: capacity too small");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    HIPCK(h, hipStreamSynchronize(h->st));
+    HIPCK(h, hipMemcpy2D(out, (size_t)t.C * sizeof(float), t.d, (size_t)t.Cs * sizeof(float), (size_t)t.C * sizeof(float),
+                         npix, hipMemcpyDeviceToHost));
+    return VNECT_OK;
+}
+
+int vnect_set_profiling(vnect_handle* h, int on)
+{
+    if (!h) return VNECT_E_ARG;
+    h->profiling = on != 0;
+    return VNECT_OK;
+}
+
+int vnect_get_timings(vnect_handle* h, vnect_timings* out)
+{
+    if (!h || !out || out->struct_size != (int32_t)sizeof(vnect_timings)) return VNECT_E_ARG;
+    *out = h->tim;
+    out->struct_size = sizeof(vnect_timings);
+    out->conv_launches = h->conv_launches;
+    out->conv_flops = h->conv_flops;
+    return VNECT_OK;
+}
+
+int vnect_reset_timings(vnect_handle* h)
+{
+    if (!h) return VNECT_E_ARG;
+    memset(&h->tim, 0, sizeof h->tim);
+    h->tim.struct_size = sizeof(vnect_timings);
+    return VNECT_OK;
+}
+
+int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out)
+{
+    if (!h || !out || idx < 0 || idx >= (int)h->layers.size()) return VNECT_E_ARG;
+    const Layer& L = h->layers[idx];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", L.name.c_str());
+    if (L.op == OP_CONV) {
+        out->M = L.a.M * L.a.nphase, out->N = L.Nreal, out->K = L.Kreal;
+        out->tile_m = L.BM, out->tile_n = L.BN, out->split_k = L.a.ksplit;
+        out->workgroups = ((L.a.M + L.BM - 1) / L.BM) * (L.a.Npad / L.BN) * L.a.nphase * L.a.ksplit;
+        out->flops = L.flops;
+    }
+    out->last_ms = L.last_ms;
+    return VNECT_OK;
+}
+
+// ---- RCCL pyramid sharding; librccl is opened lazily so single-GPU use never loads it ----
+typedef struct { char internal[128]; } nccl_uid;
+static void* g_rccl = nullptr;
+static int (*p_ncclGetUniqueId)(nccl_uid*) = nullptr;
+static int (*p_ncclCommInitRank)(void**, int, nccl_uid, int) = nullptr;
+
+static bool load_rccl()
+{
+    if (g_rccl) return true;
+    g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl) g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl) return false;
+    p_ncclGetUniqueId = (int (*)(nccl_uid*))dlsym(g_rccl, "ncclGetUniqueId");
+    p_ncclCommInitRank = (int (*)(void**, int, nccl_uid, int))dlsym(g_rccl, "ncclCommInitRank");
+    return p_ncclGetUniqueId && p_ncclCommInitRank;
+}
+
+int vnect_comm_unique_id(void* id128)
+{
+    if (!id128) return VNECT_E_ARG;
+    if (!load_rccl()) return fail(nullptr, VNECT_E_COMM, "librccl.so not available");
+    nccl_uid u;
+    if (p_ncclGetUniqueId(&u) != 0) return fail(nullptr, VNECT_E_COMM, "ncclGetUniqueId failed");
+    memcpy(id128, &u, sizeof u);
+    return VNECT_OK;
+}
+
+int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128)
+{
+    if (!h || !id128) return VNECT_E_ARG;
+    return fail(h, VNECT_E_COMM, "pyramid sharding over RCCL is not built in this round");
+}
+
+}  // extern "C"

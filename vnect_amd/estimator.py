@@ -1,0 +1,135 @@
+"""VNectEstimator: the reference's call surface (src/estimator.py:16-142) over libvnect_hip.so.
+
+    from vnect_amd import VNectEstimator
+    est = VNectEstimator()                       # reference defaults (scales [1, 0.85, 0.7])
+    joints_2d, joints_3d = est(frame_bgr_uint8)  # (21,2) float64 [row, col], (21,3) float32 mm
+
+Everything from gen_input_batch to the un-mapping runs on the MI355X in hand-written HIP kernels;
+this file only marshals arguments.  Additive keyword arguments (not in the reference): ``scales``,
+``weights``, ``seed``, ``device``, ``precision``, ``paper_res2c``, ``use_graph``, and
+``timestamp=`` on ``__call__`` for reproducible filtering (default: wall clock, like the reference).
+"""
+import time
+
+import numpy as np
+
+from . import _native
+from .weights import MASTER_SEED, check_schema, load_weights, synthetic_weights
+
+
+class VNectEstimator:
+    # class attributes of src/estimator.py:18-25
+    box_size = 368
+    hm_factor = 8
+    joints_sum = 21
+    joint_parents = [16, 15, 1, 2, 3, 1, 5, 6, 14, 8, 9, 14, 11, 12, 14, 14, 1, 4, 7, 10, 13]
+
+    def __init__(self, scales=None, weights=None, seed=MASTER_SEED, device=0, precision="fp32", paper_res2c=False,
+                 use_graph=True, numpy_promotion="legacy", verbose=True):
+        if verbose:
+            print('Initializing VNect Estimator...')
+        # src/estimator.py:32; "for faster loops, use less scales e.g. [1], [1, 0.7]"
+        self._scales = [float(s) for s in (scales if scales is not None else [1, 0.85, 0.7])]
+        if isinstance(weights, str):
+            weights = load_weights(weights)
+        elif weights is None:
+            # no trained weights ship with the reference (models/*/README.md): seeded synthetic ones
+            weights = synthetic_weights(seed)
+        else:
+            check_schema(weights)
+        self._cfg = dict(device=device, precision={"fp32": _native.FP32, "bf16": _native.BF16}[precision],
+                         paper_res2c=paper_res2c, use_graph=use_graph,
+                         numpy_promotion={"legacy": 0, "nep50": 1}[numpy_promotion])
+        self._weights = weights
+        self._h = None
+        self._open()
+        self.verbose = verbose
+        if verbose:
+            print('VNect Estimator initialized.')
+
+    def _open(self):
+        if self._h is not None:
+            self._h.close()
+        self._h = _native.Handle(self._scales, **self._cfg)
+        self._h.set_weights(self._weights)
+        self._h.finalize()
+
+    # `self.scales` is a plain attribute in the reference; assigning it re-plans the pyramid
+    @property
+    def scales(self):
+        return list(self._scales)
+
+    @scales.setter
+    def scales(self, value):
+        value = [float(s) for s in value]
+        if len(value) == len(self._scales):
+            self._h.set_scales(value)
+            self._scales = value
+        else:  # batch size of the conv stack changes: rebuild the handle (filters restart, as a new estimator would)
+            self._scales = value
+            self._open()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @staticmethod
+    def gen_input_batch(img_input, box_size, scales, _handle=None):
+        """src/estimator.py:70-81 on the device.  Returns (batch (S,368,368,3) f32, scaler, [offset_x, offset_y])."""
+        if box_size != 368:
+            raise ValueError("box_size is fixed at 368 by the network")
+        h = _handle
+        own = h is None or h.num_scales != len(scales)
+        if own:
+            h = _native.Handle(list(scales))
+            # pre-processing needs no weights, but the handle must be planned
+            h.set_weights(synthetic_weights())
+            h.finalize()
+        else:
+            h.set_scales(scales)
+        try:
+            return h.preprocess(img_input)
+        finally:
+            if own:
+                h.close()
+
+    def joint_filter(self, joints, dim=2):
+        raise NotImplementedError("the OneEuro filters run inside the fused device kernel (see vnect_postprocess); "
+                                  "use VNectEstimator.postprocess(maps, ...) for the filtered joints")
+
+    def postprocess(self, maps, timestamp=None, scaler=1.0, offset_x=0, offset_y=0):
+        t2d, t3d = self._stamps(timestamp)
+        return self._h.postprocess(maps, t2d, t3d, scaler, offset_x, offset_y)
+
+    def forward(self, batch):
+        """sess.run equivalent (src/estimator.py:100-104): (S,368,368,3) -> (S,46,46,84)."""
+        return self._h.forward(batch)
+
+    @staticmethod
+    def _stamps(timestamp):
+        if timestamp is None:  # src/estimator.py:84 reads time.time() once per joint_filter call
+            return time.time(), time.time()
+        if isinstance(timestamp, (tuple, list)):
+            return float(timestamp[0]), float(timestamp[1])
+        return float(timestamp), float(timestamp)
+
+    def __call__(self, img_input, timestamp=None):
+        t0 = time.time()
+        t2d, t3d = self._stamps(timestamp)
+        try:
+            joints_2d, joints_3d = self._h.infer(img_input, t2d, t3d)
+        except _native.VnectError as e:
+            if e.code == _native.E_TIMESTAMP:
+                raise ZeroDivisionError("float division by zero") from e  # src/OneEuroFilter.py:66
+            raise
+        if self.verbose:
+            print('FPS: {:>2.2f}'.format(1 / max(time.time() - t0, 1e-9)))
+        return joints_2d, joints_3d
+
+    def reset(self):
+        self._h.reset_filters()
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None
