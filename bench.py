@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of 368x368, 3-scale VNect inference on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step is one pass of the hot path (VNectEstimator.__call__, /root/reference/src/estimator.py:97-142) over one
+synthetic 368x368 BGR frame at scales [1.0, 0.8, 0.6], fp32 (BASELINE.json configs[1]).  Frames are resident in
+HBM before the timed region; each step ends with the 21x2 + 21x3 joints back on the host (synchronous, as the
+reference's tracking loop consumes them).  N>1 = N independent streams, one per GPU (weak scaling, no
+collective on the data path; BASELINE.json configs[4]).  Weights are seeded synthetic (none ship with the reference).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCALES = [1.0, 0.8, 0.6]
+FLOPS_PER_FRAME = 71.49e9      # 23.83 GFLOP per image x 3 scales (live graph, 2*MAC)
+PEAK_FP32_MFMA = 157.3         # TFLOP/s, MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
+
+
+def cpu_baseline(weights, budget_s):
+    """The CPU oracle (a port of the reference path; TF1 itself cannot run here) on this box's host cores."""
+    import oracle
+    from tests import helpers
+    est = oracle.OracleEstimator(weights=weights, scales=SCALES)
+    frames = [helpers.synth_frame(1234 + k) for k in range(4)]
+    est(frames[0], 1.0, 1.0)  # warm-up (page-in, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        est(frames[n % 4], 2.0 + n / 30, 2.0 + n / 30)
+        n += 1
+        dt = time.perf_counter() - t0
+        if (dt >= budget_s and n >= 3) or n >= 400:
+            break
+    cores = oracle.lib().vo_sgemm_threads()
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same workload in %.1f s (C/OpenMP fp32 oracle, AVX2/AVX-512 SGEMM)" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from tests import helpers
+    from vnect_amd import _native
+    from vnect_amd.weights import synthetic_weights
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    weights = synthetic_weights()
+    h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8)
+    h.set_weights(weights)
+    h.finalize()
+    # one synthetic video stream per rank: seeds 1234 + 1000*stream
+    nslots = 8
+    for k in range(nslots):
+        h.upload_frame(k, helpers.synth_frame(1234 + 1000 * rank + k))
+
+    t = 1.7e9
+    for i in range(args.warmup):
+        t += 1 / 30
+        h.infer_resident(i % nslots, t, t + 1e-3)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        t += 1 / 30
+        j2, j3 = h.infer_resident(i % nslots, t, t + 1e-3)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+    assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
+
+    # two-deep pipelined rate of the same stream (submit k+1 before collecting k), reported beside the serial one
+    barrier()
+    p0 = time.perf_counter()
+    h.submit_resident(0, t + 1, t + 1 + 1e-3)
+    for i in range(1, args.steps):
+        h.submit_resident(i % nslots, t + 1 + i / 30, t + 1 + i / 30 + 1e-3)
+        h.collect()
+    h.collect()
+    torch.cuda.synchronize()
+    pipelined = args.steps / (time.perf_counter() - p0)
+
+    out = None
+    if rank == 0:
+        # dominant kernel = the conv stack (conv_f32_kernel<BM,BN>, ~53 launches per frame): HIP events on the
+        # library's stream around every layer, over frames of the same workload
+        h.set_profiling(True)
+        h.reset_timings()
+        nprof = min(max(args.steps // 4, 10), 100)
+        conv_ms = 0.0
+        for i in range(nprof):
+            t += 1 / 30
+            h.infer_resident(i % nslots, t + 10, t + 10 + 1e-3)
+            conv_ms += sum(L["last_ms"] for L in h.layers() if L["flops"] > 0)
+        tim = h.timings()
+        h.set_profiling(False)
+        conv_ms /= nprof
+        achieved = FLOPS_PER_FRAME / (conv_ms * 1e-3) / 1e12
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tj):
+            traffic = json.load(open(tj)).get("hbm_bytes_per_frame")
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "frames/sec, 368x368 3-scale VNect inference", "value": round(args.gpus * args.steps / elapsed, 2),
+            "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "368x368x3 uint8 BGR frame -> 21 joints; scales [1.0,0.8,0.6]; fp32; batch 1 "
+                                   "(BASELINE.json configs[1]); N>1 = N independent streams, one per GPU",
+                       "weights": "seeded synthetic (reference ships none)", "frames_resident_in_hbm": True,
+                       "hip_graph": not args.no_graph, "sync_per_frame": True},
+            "pipelined_frames_per_s_per_gpu": round(pipelined, 2),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+                         "kernel": "conv_f32_kernel<BM,BN> (%d conv launches per frame)" % tim["conv_launches"],
+                         "kernel_ms_per_frame": round(conv_ms, 4), "flops_per_frame": FLOPS_PER_FRAME,
+                         "stage_ms": {"pre": round(tim["pre_ms"] / nprof, 4), "net": round(tim["net_ms"] / nprof, 4),
+                                      "post": round(tim["post_ms"] / nprof, 4)}},
+        }
+    h.close()
+    if rank == 0:
+        if args.cpu_seconds > 0 and args.gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(weights, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,9 @@ def test_conv_stack_every_layer(h3, oracle_net):
     names = [L["name"] for L in h3.layers()]
     acts = ["conv1", "pool1"]
     for n in names:
-        if n.endswith("_branch2c") or n == "res5a_branch2c_new":
+        if n == "res5c_branch2c":
+            acts.append(n)
+        elif n.endswith("_branch2c") or n == "res5a_branch2c_new":
             acts.append(n.split("_")[0])      # block output resNx
         elif n == "res5c_deconv":
             continue

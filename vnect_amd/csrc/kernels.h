@@ -23,6 +23,7 @@ struct ConvArgs {
     const float* resid;   // nullptr or same pixel indexing as out
     float* out;
     float* ws;            // split-K workspace [ksplit][out pixels][Npad]
+    const float* zeros;   // >= 128 B of zeros (source of padded taps / rows past M for the LDS-DMA loads)
     int S, H, W, Cs;      // input grid, floats per input pixel
     int Ho, Wo, M;        // logical output grid, M = S*Ho*Wo
     int K, ntaps, cpt;    // K = ntaps*cpt*32
@@ -34,8 +35,12 @@ struct ConvArgs {
     int ksplit;
     int relu_cols;        // ReLU on columns < relu_cols
     int pixmode;          // conv1: a 32-float chunk is 8 consecutive NHWC4 pixels of one input row
+    int impl;             // 0 = LDS-DMA ring kernel (default), 1 = register-staged kernel (A/B reference)
+    int deep;             // LDS ring depth: -1 auto, 0 shallow (2 workgroups per CU), 1 deep (1 per CU)
+    int tiles_m, tiles_n; // filled by the launcher
+    int ablate;           // tuning only (VNECT_ABLATE): 1 no MFMA, 2 no fragment reads, 4 no in-loop DMA, 8 no in-loop barrier
     long long w_phase_stride;
-    int8_t dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]
+    int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

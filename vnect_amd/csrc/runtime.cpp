@@ -66,6 +66,7 @@ struct vnect_handle {
     float* in3 = nullptr;  // (S,368,368,3) staging for vnect_forward / preprocess read-back
     float* ws = nullptr;
     size_t ws_floats = 0;
+    float* zeros = nullptr;
     std::vector<void*> dev_allocs;
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
@@ -381,7 +382,7 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     if (conv1) {
         // K = 7 rows x (8 pixels x 4 channels): pixel 7 and channel 3 carry zero weights
         a.pixmode = 1, a.ntaps = 7, a.cpt = 1, cp = 32;
-        for (int ky = 0; ky < 7; ky++) a.dy[ky] = (int8_t)(ky - pt), a.dx[ky] = (int8_t)(-pl);
+        for (int ky = 0; ky < 7; ky++) a.dy[ky] = (int)(ky - pt), a.dx[ky] = (int)(-pl);
     } else {
         cp = round_up(tin.Cs, 32);
         if (cp != tin.Cs) {
@@ -390,7 +391,7 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
         }
         a.pixmode = 0, a.ntaps = sp.k * sp.k, a.cpt = cp / 32;
         for (int ky = 0; ky < sp.k; ky++)
-            for (int kx = 0; kx < sp.k; kx++) a.dy[ky * sp.k + kx] = (int8_t)(ky - pt), a.dx[ky * sp.k + kx] = (int8_t)(kx - pl);
+            for (int kx = 0; kx < sp.k; kx++) a.dy[ky * sp.k + kx] = (int)(ky - pt), a.dx[ky * sp.k + kx] = (int)(kx - pl);
     }
     a.K = a.ntaps * a.cpt * 32;
     L.Kreal = sp.k * sp.k * cin;
@@ -536,7 +537,7 @@ int finalize_impl(vnect_handle* h)
                 for (int ta = 0; ta < 2; ta++)
                     for (int tb = 0; tb < 2; tb++) {
                         const int t = ta * 2 + tb, ky = kys[py][ta], kx = kys[px][tb];
-                        a.dy[z * 4 + t] = (int8_t)dys[py][ta], a.dx[z * 4 + t] = (int8_t)dys[px][tb];
+                        a.dy[z * 4 + t] = (int)dys[py][ta], a.dx[z * 4 + t] = (int)dys[px][tb];
                         for (int n = 0; n < 191; n++) {
                             const float* src = n < 128 ? &W2->d[(((size_t)ky * 4 + kx) * 128 + n) * 256]
                                                        : &W1->d[(((size_t)ky * 4 + kx) * 63 + (n - 128)) * 256];
@@ -590,14 +591,24 @@ int finalize_impl(vnect_handle* h)
         int rc = dev_alloc(h, &h->ws, ws);
         if (rc) return rc;
     }
+    {
+        int rc = dev_alloc(h, &h->zeros, 256);
+        if (rc) return rc;
+        HIPCK(h, hipMemset(h->zeros, 0, 256 * sizeof(float)));
+    }
     HIPCK(h, hipDeviceSynchronize());
+    const char* impl_env = getenv("VNECT_CONV_IMPL");  // "reg" selects the register-staged kernel (A/B reference)
+    const int impl = impl_env && !strcmp(impl_env, "reg") ? 1 : 0;
     h->conv_flops = 0, h->conv_launches = 0;
     for (Layer& L : h->layers) {
         if (L.op != OP_CONV) continue;
         ConvArgs& a = L.a;
         a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
         a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
-        a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws;
+        a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws, a.zeros = h->zeros;
+        a.impl = impl;
+        a.deep = getenv("VNECT_DEEP") ? atoi(getenv("VNECT_DEEP")) : -1;
+        a.ablate = getenv("VNECT_ABLATE") ? atoi(getenv("VNECT_ABLATE")) : 0;
         if (a.ksplit > 1) {
             ReduceArgs& q = L.r;
             q.ws = h->ws, q.bias = L.bias, q.scale = L.scale, q.shift = L.shift, q.resid = a.resid, q.out = a.out;
