@@ -5,12 +5,11 @@
 // of src/vnect_model.py:25-217: Conv2D(+BiasAdd+Add+Relu), Conv2DBackpropInput (as 4 sub-pixel phases),
 // FusedBatchNorm (folded into the epilogue), MaxPool, and the bone-length Mul/Add/Sqrt/Concat.
 //
-// Tiling: one 256-thread workgroup = 4 waves (2x2) computes a BM x BN output tile; each wave owns
-// (BM/2)x(BN/2) as 32x32 MFMA accumulators.  K runs in 32-float chunks: a chunk is one filter tap and
-// 32 consecutive input channels, i.e. one 128-byte run per NHWC input pixel, so global reads are
-// whole cache lines.  A (gathered activation rows) and B (pre-packed weights, [N][K]) chunks are
-// register-staged into a double-buffered LDS image with a 36-float row pitch: ds_write_b128 by 8-lane
-// row groups and ds_read_b128 by MFMA lane groups are both bank-conflict free at that pitch.
+// Tiling: one 512-thread workgroup computes a BM x BN output tile: 4 consumer waves (2x2, one per SIMD) own
+// (BM/2)x(BN/2) each as 32x32 MFMA accumulators, 4 producer waves feed them.  K runs in 32-float chunks: a
+// chunk is one filter tap and 32 consecutive input channels, i.e. one 128-byte run per NHWC input pixel, so
+// global reads are whole cache lines.  A (gathered activation rows) and B (pre-packed weights, [N][K])
+// chunks go global -> LDS by LDS-DMA into a ring of stages (details at the kernel).
 #include "kernels.h"
 
 namespace vnect {
@@ -20,221 +19,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDT = 36;  // LDS row pitch in floats (32 + 4)
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a)
-{
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [2][BM][LDT]
-    float* Bs = smem + 2 * BM * LDT;  // [2][BN][LDT]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int phase = blockIdx.z / a.ksplit, ks = blockIdx.z - phase * a.ksplit;
-    const int nch = a.ntaps * a.cpt;
-    const int c0 = (int)(((long long)nch * ks) / a.ksplit);
-    const int c1 = (int)(((long long)nch * (ks + 1)) / a.ksplit);
-    const int lrow = tid >> 3, col4 = tid & 7;
-    const int pix = a.pixmode;
-
-    // rows of the A tile this thread stages (same rows for every chunk)
-    int a_iy[AR], a_ix[AR], a_pix[AR];
-#pragma unroll
-    for (int i = 0; i < AR; i++) {
-        int m = m0 + lrow + 32 * i;
-        if (m < a.M) {
-            int ox = m % a.Wo, t = m / a.Wo;
-            int oy = t % a.Ho, s = t / a.Ho;
-            a_iy[i] = oy * a.stride;
-            a_ix[i] = ox * a.stride + (pix ? col4 : 0);
-            a_pix[i] = s * a.H * a.W;
-        } else {
-            a_iy[i] = -(1 << 20);  // fails the bounds test for every tap -> zeros
-            a_ix[i] = 0;
-            a_pix[i] = 0;
-        }
-    }
-    const float* __restrict__ inp = a.in;
-    const float* __restrict__ wp =
-        a.w + (long long)phase * a.w_phase_stride + (long long)(n0 + lrow) * a.K + col4 * 4 + (long long)c0 * 32;
-    const int* dyp = a.dy + phase * a.ntaps;
-    const int* dxp = a.dx + phase * a.ntaps;
-
-    // gather cursor of the NEXT chunk to load: per-row element offsets are recomputed only when the tap changes
-    int tap = c0 / a.cpt, cc = c0 - tap * a.cpt;
-    int a_off[AR];
-    bool a_ok[AR];
-    auto set_tap = [&](int t) {
-        const int dy = dyp[t], dx = dxp[t];
-#pragma unroll
-        for (int i = 0; i < AR; i++) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            a_ok[i] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            a_off[i] = (a_pix[i] + iy * a.W + ix) * a.Cs + (pix ? 0 : col4 * 4);
-        }
-    };
-    f32x4 ra[AR], rb[BR];
-    auto gload = [&]() {
-#pragma unroll
-        for (int i = 0; i < AR; i++) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok[i]) v = *(const f32x4*)(inp + a_off[i] + cc * 32);
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; i++) rb[i] = *(const f32x4*)(wp + (long long)i * 32 * a.K);
-        wp += 32;
-        if (++cc == a.cpt) {
-            cc = 0;
-            if (++tap < a.ntaps) set_tap(tap);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AR; i++) *(f32x4*)&As[(buf * BM + lrow + 32 * i) * LDT + col4 * 4] = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; i++) *(f32x4*)&Bs[(buf * BN + lrow + 32 * i) * LDT + col4 * 4] = rb[i];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    // MFMA operand map (32x32x2 f32): lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31].
-    // Within a 32-deep chunk, lane half h reads the float4 at k = 8q + 4h .. +3 (q = 0..3) of its row for
-    // both operands, so MFMA step (q, e) contracts k = 8q + e (h = 0) and k = 8q + 4 + e (h = 1).
-    const int frag_off = (lane & 31) * LDT + 4 * (lane >> 5);
-    auto rfrag = [&](int buf, int q, f32x4(&af)[TM], f32x4(&bf)[TN]) {
-        const float* Ab = As + (buf * BM + wm * WM) * LDT + frag_off + 8 * q;
-        const float* Bb = Bs + (buf * BN + wn * WN) * LDT + frag_off + 8 * q;
-#pragma unroll
-        for (int i = 0; i < TM; i++) af[i] = *(const f32x4*)(Ab + i * 32 * LDT);
-#pragma unroll
-        for (int j = 0; j < TN; j++) bf[j] = *(const f32x4*)(Bb + j * 32 * LDT);
-    };
-    auto mma = [&](const f32x4(&af)[TM], const f32x4(&bf)[TN]) {
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-    };
-
-    // Software pipeline (one barrier per 32-deep chunk): while the MFMAs of chunk c run from LDS buffer b,
-    // chunk c+1 moves registers -> LDS buffer b^1 and chunk c+2 moves global -> registers; the fragments of
-    // the next 8-deep step are always read one step ahead, so no LDS or global latency sits in front of an MFMA.
-    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    if (c0 < c1) {
-        set_tap(tap);
-        gload();
-        lstore(0);
-        if (c0 + 1 < c1) gload();
-    }
-    __syncthreads();
-    if (c0 < c1) rfrag(0, 0, fa0, fb0);
-    for (int c = c0; c < c1; c++) {
-        const int buf = (c - c0) & 1;
-        rfrag(buf, 1, fa1, fb1);
-        mma(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        rfrag(buf, 2, fa0, fb0);
-        mma(fa1, fb1);
-        if (c + 1 < c1) lstore(buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        rfrag(buf, 3, fa1, fb1);
-        mma(fa0, fb0);
-        if (c + 2 < c1) gload();
-        __syncthreads();
-        if (c + 1 < c1) rfrag(buf ^ 1, 0, fa0, fb0);
-        mma(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // Epilogue.  C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Each 32x32 accumulator goes
-    // through a wave-private LDS scratch so that global traffic is 16 B per lane along N (8 lanes = one 128-B line).
-    const int py = phase >> 1, px = phase & 1;
-    const bool direct = (a.os == 1);
-    const long long npix = (long long)a.S * a.OH * a.OW;
-    const float* __restrict__ resid = a.resid;
-    const bool fused = a.ksplit == 1;
-    float* __restrict__ outp = fused ? a.out : a.ws + (long long)ks * npix * a.Npad;
-    const int ldo = fused ? a.ldc : a.Npad;
-    const int nlim = fused ? a.Nvalid : a.Npad;
-    float* scr = smem + wave * (32 * LDT);  // the pipeline buffers are dead: every wave passed the last barrier
-    const int erow = lane >> 3, ecol = (lane & 7) * 4;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * WN + j * 32 + ecol;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, s4 = {1.f, 1.f, 1.f, 1.f}, h4 = {0.f, 0.f, 0.f, 0.f};
-        if (fused) {
-            b4 = *(const f32x4*)(a.bias + n);
-            if (a.scale) s4 = *(const f32x4*)(a.scale + n), h4 = *(const f32x4*)(a.shift + n);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous scratch reads retired
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                scr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[i][j][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            f32x4 v[4], rs[4];
-            long long op[4];
-            bool ok[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int row = erow + 8 * k;
-                const int m = m0 + wm * WM + i * 32 + row;
-                v[k] = *(const f32x4*)&scr[row * LDT + ecol];
-                ok[k] = m < a.M && n < nlim;
-                op[k] = m;
-                if (!direct) {
-                    int ox = m % a.Wo, t = m / a.Wo;
-                    int oy = t % a.Ho, s = t / a.Ho;
-                    op[k] = ((long long)s * a.OH + oy * a.os + py) * a.OW + ox * a.os + px;
-                }
-            }
-            const bool vec = n + 3 < nlim;
-            if (fused && resid) {  // shortcut loads all in flight before the first use
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    rs[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ok[k]) rs[k] = *(const f32x4*)(resid + op[k] * a.ldr + n);  // shortcut layers have Nvalid % 4 == 0
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                f32x4 o = v[k];
-                if (fused) {
-                    o = o + b4;
-                    if (a.scale) o = o * s4 + h4;
-                    if (resid) o = o + rs[k];
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (n + e < a.relu_cols) o[e] = o[e] > 0.f ? o[e] : 0.f;
-                }
-                if (!ok[k]) continue;
-                float* dst = outp + op[k] * ldo + n;
-                if (vec) {
-                    *(f32x4*)dst = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (n + e < nlim) dst[e] = o[e];
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (default): chunks go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into
+// Chunks go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into
 // an NS-deep ring, issued NS-1 chunks ahead with counted vmcnt waits, one raw s_barrier per chunk.  The LDS
 // image is lane-linear per wave-instruction (8 rows x 128 B); bank conflicts are removed by fetching, for LDS
 // slot (row r, 16-B unit u'), the SOURCE unit u = u' ^ ((r >> 1) & 7) and applying the same XOR on the
@@ -251,7 +37,7 @@ __device__ __forceinline__ void wait_vm()
 }
 
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void conv_f32_glds_kernel(const ConvArgs a)
+__global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
 {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;  // floats per ring stage (128-B rows, no padding)
@@ -259,11 +45,19 @@ __global__ __launch_bounds__(256) void conv_f32_glds_kernel(const ConvArgs a)
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Wave specialisation: waves 0-3 are CONSUMERS (one per SIMD: fragment reads + MFMA + epilogue), waves 4-7 are
+    // PRODUCERS (one per SIMD: LDS-DMA issue + landing waits).  An LDS-DMA instruction costs its wave ~100-200
+    // issue cycles; in a wave that also owns the MFMA chain that stall idles the matrix pipe, in a partner wave
+    // it does not.  All 8 waves meet at one s_barrier per 32-deep chunk.
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const bool producer = threadIdx.x >= 256;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order (speed only): workgroup ids are dealt round-robin over the 8 XCDs, so give every
-    // XCD a contiguous run of the logical tile sequence (N-tile fastest): tiles that share an activation row
-    // block, and all weight tiles, then meet in one XCD's L2.  Bijective for any grid size.
+    // XCD-aware tile order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs,
+    // so give every XCD a contiguous run of the logical tile sequence (N-tile fastest, then M, then K-slice /
+    // phase): tiles that share an activation row block, and all weight tiles, then meet in one XCD's L2.
+    // Bijective for any grid size.  (A row-band-per-XCD order that keeps each XCD on the rows it wrote one layer
+    // earlier was measured too: no gain -- operand residency is not what limits this kernel -- and it unbalances
+    // layers with few M tiles.)
     int tile_m, tile_n, zz;
     {
         const int nwg = gridDim.x, id = blockIdx.x;
@@ -350,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_f32_glds_kernel(const ConvArgs a)
 
     // shortcut tile: loaded now (ordinary loads, ahead of the LDS-DMA queue) so the epilogue never waits for it
     const bool fused = a.ksplit == 1;
-    const bool has_res = fused && a.resid != nullptr;
+    const bool has_res = fused && a.resid != nullptr && !producer;
     const int nlim = fused ? a.Nvalid : a.Npad;
     const int erow = lane >> 3, ecol = (lane & 7) * 4;
     f32x4 rs[TM][TN][4];
@@ -382,9 +176,7 @@ __global__ __launch_bounds__(256) void conv_f32_glds_kernel(const ConvArgs a)
     int fo[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) fo[q] = (lane & 31) * 32 + (((2 * q + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4);
-    const int abl = a.ablate;
     auto rfrag = [&](int stage, int q, f32x4(&af)[TM], f32x4(&bf)[TN]) {
-        if (abl & 2) return;
         const float* Ab = smem + stage * STAGE + (wm * WM) * 32 + fo[q];
         const float* Bb = smem + stage * STAGE + (BM + wn * WN) * 32 + fo[q];
 #pragma unroll
@@ -393,7 +185,6 @@ __global__ __launch_bounds__(256) void conv_f32_glds_kernel(const ConvArgs a)
         for (int j = 0; j < TN; j++) bf[j] = *(const f32x4*)(Bb + j * (32 * 32));
     };
     auto mma = [&](const f32x4(&af)[TM], const f32x4(&bf)[TN]) {
-        if (abl & 1) return;
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -403,43 +194,58 @@ __global__ __launch_bounds__(256) void conv_f32_glds_kernel(const ConvArgs a)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     };
 
-    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    if (producer) {
+        // ---- producer waves: keep NS-1 chunks in flight, publish chunk t+1 at barrier t --------------------
+        set_tap(tap);
 #pragma unroll
-    for (int i = 0; i < TM; i++) fa0[i] = fa1[i] = (f32x4){1.f, 2.f, 3.f, 4.f};
-#pragma unroll
-    for (int j = 0; j < TN; j++) fb0[j] = fb1[j] = (f32x4){1.f, 2.f, 3.f, 4.f};
-    set_tap(tap);
-#pragma unroll
-    for (int p = 0; p < NS - 1; p++)
-        if (p < total) issue(p);
-    wait_landed(total - 1 < NS - 2 ? total - 1 : NS - 2);
-    __builtin_amdgcn_s_barrier();
-    rfrag(0, 0, fa0, fb0);
-    int stage = 0;
-    for (int t = 0; t < total; t++) {
-        const int nstage = stage + 1 == NS ? 0 : stage + 1;
-        rfrag(stage, 1, fa1, fb1);
-        mma(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        rfrag(stage, 2, fa0, fb0);
-        mma(fa1, fb1);
-        if (t + 1 < total) {
-            // chunk t+1 must be complete in LDS; younger chunks in flight: t+2 .. min(t+NS-2, total-1)
+        for (int p = 0; p < NS - 1; p++)
+            if (p < total) issue(p);
+        wait_landed(total - 1 < NS - 2 ? total - 1 : NS - 2);
+        __builtin_amdgcn_s_barrier();  // chunk 0 visible
+        int stage = 0;
+        for (int t = 0; t + 1 < total; t++) {
+            // chunk t+1 complete in LDS; younger chunks still in flight: t+2 .. min(t+NS-2, total-1)
             const int young = total - 2 - t;
-            if (!(abl & 8)) {
-                wait_landed(young < NS - 3 ? young : NS - 3);
-                __builtin_amdgcn_s_barrier();  // everyone is past chunk t-1, whose stage is refilled next
-            }
-            if (t + NS - 1 < total && !(abl & 4)) issue(stage == 0 ? NS - 1 : stage - 1);
+            wait_landed(young < NS - 3 ? young : NS - 3);
+            __builtin_amdgcn_s_barrier();  // consumers are past chunk t-1: its stage may be refilled
+            if (t + NS - 1 < total) issue(stage == 0 ? NS - 1 : stage - 1);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+        __builtin_amdgcn_s_barrier();  // matches the consumers' ring-is-dead barrier
+        return;
+    }
+
+    // ---- consumer waves ------------------------------------------------------------------------------------
+    // All fragments of chunk t+1 (8 x ds_read_b128 for a 32x32 wave tile) are requested right after the barrier
+    // that publishes it, i.e. half a chunk of MFMAs before their first use; two register sets alternate.
+    struct Frag {
+        f32x4 a[4][TM], b[4][TN];
+    };
+    Frag F0, F1;
+    auto rall = [&](int stg, Frag& F) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) rfrag(stg, q, F.a[q], F.b[q]);
+    };
+    int stage = 0;
+    auto step = [&](Frag& cur, Frag& nxt, int t) {
+        const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        mma(cur.a[0], cur.b[0]);
+        mma(cur.a[1], cur.b[1]);
+        if (t + 1 < total) {
+            __builtin_amdgcn_s_barrier();  // chunk t+1 visible; every consumer is past chunk t-1
+            rall(nstage, nxt);
         }
         __builtin_amdgcn_sched_barrier(0);
-        rfrag(stage, 3, fa1, fb1);
-        mma(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < total) rfrag(nstage, 0, fa0, fb0);
-        mma(fa1, fb1);
+        mma(cur.a[2], cur.b[2]);
+        mma(cur.a[3], cur.b[3]);
         __builtin_amdgcn_sched_barrier(0);
         stage = nstage;
+    };
+    __builtin_amdgcn_s_barrier();  // chunk 0 visible
+    rall(0, F0);
+    for (int t = 0; t < total; t += 2) {
+        step(F0, F1, t);
+        if (t + 1 < total) step(F1, F0, t + 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // ring is dead: reuse it as the epilogue scratch
@@ -510,11 +316,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
          idx += (long long)gridDim.x * blockDim.x) {
         const long long pix = idx / n4;
         const int n = (int)(idx - pix * n4) * 4;
-        f32x4 s = *(const f32x4*)(a.ws + pix * a.Npad + n);
-        for (int k = 1; k < a.ksplit; k++) {
-            f32x4 t = *(const f32x4*)(a.ws + ((long long)k * a.npix + pix) * a.Npad + n);
-            s += t;
-        }
+        f32x4 part[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)  // all slab loads in flight at once
+            if (k < a.ksplit) part[k] = *(const f32x4*)(a.ws + ((long long)k * a.npix + pix) * a.Npad + n);
+        f32x4 s = part[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++)  // summed in slice order: deterministic
+            if (k < a.ksplit) s += part[k];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int c = n + e;
@@ -528,39 +337,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
     }
 }
 
-template <int BM, int BN>
-static hipError_t launch_t(const ConvArgs& a, hipStream_t st)
-{
-    dim3 grid((a.M + BM - 1) / BM, a.Npad / BN, a.nphase * a.ksplit);
-    size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-    hipLaunchKernelGGL((conv_f32_kernel<BM, BN>), grid, dim3(256), lds, st, a);
-    return hipGetLastError();
-}
 template <int BM, int BN, int NS>
 static hipError_t launch_g(ConvArgs a, hipStream_t st)
 {
     a.tiles_m = (a.M + BM - 1) / BM, a.tiles_n = a.Npad / BN;
     dim3 grid(a.tiles_m * a.tiles_n * a.nphase * a.ksplit);
     size_t lds = (size_t)NS * (BM + BN) * 32 * sizeof(float);
-    hipLaunchKernelGGL((conv_f32_glds_kernel<BM, BN, NS>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_f32_glds_kernel<BM, BN, NS>), grid, dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
+// Ring depths leave room for two workgroups per CU (<= 80 KiB each): measured faster than one deep ring per CU
+// on every layer of the network (tools/sweep.sh).
 hipError_t conv_setup()
 {
     hipError_t e;
-#define SET(BM, BN)                                                                                  \
-    e = hipFuncSetAttribute((const void*)conv_f32_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            2 * (BM + BN) * LDT * (int)sizeof(float));                                \
-    if (e != hipSuccess) return e;
-    SET(64, 64) SET(128, 64) SET(64, 128) SET(128, 128)
-#undef SET
 #define SETG(BM, BN, NS)                                                                                       \
     e = hipFuncSetAttribute((const void*)conv_f32_glds_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             NS * (BM + BN) * 32 * (int)sizeof(float));                                          \
     if (e != hipSuccess) return e;
-    SETG(64, 64, 5) SETG(64, 64, 8) SETG(128, 64, 3) SETG(128, 64, 6) SETG(64, 128, 3) SETG(64, 128, 6)
-    SETG(128, 128, 3) SETG(128, 128, 4)
+    SETG(64, 64, 5) SETG(128, 64, 3) SETG(64, 128, 3)
 #undef SETG
     return hipSuccess;
 }
@@ -570,21 +366,9 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
     if (a.Npad % BN != 0 || a.K % 32 != 0 || a.K != a.ntaps * a.cpt * 32 || a.nphase * a.ntaps > MAX_TAPS ||
         a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || !a.zeros)
         return hipErrorInvalidValue;
-    if (a.impl == 0) {
-        // ring depth: few workgroups (<= one per CU) -> one deep ring per CU (bytes in flight hide the ~1.5 us
-        // LDS-DMA latency); many workgroups -> shallower rings so two workgroups share a CU
-        const long long wgs = (long long)((a.M + BM - 1) / BM) * (a.Npad / BN) * a.nphase * a.ksplit;
-        const bool deep = a.deep >= 0 ? a.deep != 0 : wgs <= 320;
-        if (BM == 64 && BN == 64) return deep ? launch_g<64, 64, 8>(a, st) : launch_g<64, 64, 5>(a, st);
-        if (BM == 128 && BN == 64) return deep ? launch_g<128, 64, 6>(a, st) : launch_g<128, 64, 3>(a, st);
-        if (BM == 64 && BN == 128) return deep ? launch_g<64, 128, 6>(a, st) : launch_g<64, 128, 3>(a, st);
-        if (BM == 128 && BN == 128) return deep ? launch_g<128, 128, 4>(a, st) : launch_g<128, 128, 3>(a, st);
-    } else {
-        if (BM == 64 && BN == 64) return launch_t<64, 64>(a, st);
-        if (BM == 128 && BN == 64) return launch_t<128, 64>(a, st);
-        if (BM == 64 && BN == 128) return launch_t<64, 128>(a, st);
-        if (BM == 128 && BN == 128) return launch_t<128, 128>(a, st);
-    }
+    if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);
+    if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
+    if (BM == 64 && BN == 128) return launch_g<64, 128, 3>(a, st);
     return hipErrorInvalidValue;
 }
 

@@ -10,6 +10,7 @@ constexpr int HM = 46;
 constexpr int NJ = 21;
 constexpr int MAPC = 84;       // 4 maps x 21 joints
 constexpr int ARG_SLABS = 8;   // row slabs per joint in the arg-max kernel (368 / 8 = 46 rows each)
+constexpr int ARG_XBLOCKS = 3; // 128-column blocks per slab
 constexpr int MAX_TAPS = 16;
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
@@ -35,10 +36,7 @@ struct ConvArgs {
     int ksplit;
     int relu_cols;        // ReLU on columns < relu_cols
     int pixmode;          // conv1: a 32-float chunk is 8 consecutive NHWC4 pixels of one input row
-    int impl;             // 0 = LDS-DMA ring kernel (default), 1 = register-staged kernel (A/B reference)
-    int deep;             // LDS ring depth: -1 auto, 0 shallow (2 workgroups per CU), 1 deep (1 per CU)
     int tiles_m, tiles_n; // filled by the launcher
-    int ablate;           // tuning only (VNECT_ABLATE): 1 no MFMA, 2 no fragment reads, 4 no in-loop DMA, 8 no in-loop barrier
     long long w_phase_stride;
     int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
 };

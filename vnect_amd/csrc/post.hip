@@ -142,51 +142,60 @@ hipError_t launch_merge(const float* maps, const MergeTabs* tabs, double* avg, i
 // thread evaluates cv2's f64 bilinear at its pixels and keeps (max value, lowest flat index).
 __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-__global__ __launch_bounds__(256) void argmax_kernel(const double* __restrict__ avg, const UpTab* __restrict__ up,
+// One thread = one column x of the virtual 368x368 upsample, for one 46-row slab of one joint.  cv2's resize is
+// separable: the horizontal pass h(sy) = M[sy][sx]*a0 + M[sy][sx+1]*a1 is evaluated once per source row and
+// reused by the (up to 8) destination rows that blend it, exactly as resize.cpp does it.
+__global__ __launch_bounds__(128) void argmax_kernel(const double* __restrict__ avg, const UpTab* __restrict__ up,
                                                      ArgPartial* __restrict__ part)
 {
     __shared__ double map[HM * HM];
-    __shared__ double sv[256];
-    __shared__ int si[256];
-    const int j = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
-    for (int p = tid; p < HM * HM; p += 256) map[p] = avg[(long long)p * NJ + j];  // heatmap = avg[0]
+    __shared__ double sv[128];
+    __shared__ int si[128];
+    const int j = blockIdx.x, slab = blockIdx.y, xb = blockIdx.z, tid = threadIdx.x;
+    for (int p = tid; p < HM * HM; p += 128) map[p] = avg[(long long)p * NJ + j];  // heatmap = avg[0]
     __syncthreads();
     constexpr int ROWS = BOX / ARG_SLABS;
-    const int y0 = slab * ROWS;
+    const int x = xb * 128 + tid;
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
-    for (int p = tid; p < ROWS * BOX; p += 256) {
-        const int y = y0 + p / BOX, x = p % BOX;
-        const double* R0 = map + up->sy0[y] * HM;
-        const double* R1 = map + up->sy1[y] * HM;
-        const int sx = up->sx[x];
-        double r0, r1;
-        if (up->edge[x]) {
-            r0 = R0[sx];
-            r1 = R1[sx];
-        } else {
-            const double a0 = up->a0[x], a1 = up->a1[x];
-            r0 = R0[sx] * a0 + R0[sx + 1] * a1;
-            r1 = R1[sx] * a0 + R1[sx + 1] * a1;
+    if (x < BOX) {
+        const int sx = up->sx[x], edge = up->edge[x];
+        const double a0 = up->a0[x], a1 = up->a1[x];
+        auto hrow = [&](int sy) {
+            const double* R = map + sy * HM;
+            return edge ? R[sx] : R[sx] * a0 + R[sx + 1] * a1;
+        };
+        int c0 = -1, c1 = -1;
+        double h0 = 0, h1 = 0;
+        for (int y = slab * ROWS; y < (slab + 1) * ROWS; y++) {
+            const int s0 = up->sy0[y], s1 = up->sy1[y];  // uniform over the block
+            if (s0 != c0) {
+                h0 = s0 == c1 ? h1 : hrow(s0);
+                c0 = s0;
+            }
+            if (s1 != c1) {
+                h1 = s1 == c0 ? h0 : hrow(s1);
+                c1 = s1;
+            }
+            const double v = h0 * up->b0[y] + h1 * up->b1[y];
+            if (v > bv) bv = v, bi = y * BOX + x;  // rows ascend: strict > keeps the first maximum of this column
         }
-        const double v = r0 * up->b0[y] + r1 * up->b1[y];
-        const int idx = y * BOX + x;
-        if (better(v, idx, bv, bi)) bv = v, bi = idx;
     }
     sv[tid] = bv, si[tid] = bi;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 64; s > 0; s >>= 1) {
         if (tid < s && better(sv[tid + s], si[tid + s], sv[tid], si[tid])) sv[tid] = sv[tid + s], si[tid] = si[tid + s];
         __syncthreads();
     }
     if (tid == 0) {
-        part[j * ARG_SLABS + slab].v = sv[0];
-        part[j * ARG_SLABS + slab].idx = si[0];
+        ArgPartial& o = part[(j * ARG_SLABS + slab) * ARG_XBLOCKS + xb];
+        o.v = sv[0];
+        o.idx = si[0];
     }
 }
 hipError_t launch_argmax(const double* avg, const UpTab* up, ArgPartial* part, hipStream_t st)
 {
-    hipLaunchKernelGGL(argmax_kernel, dim3(NJ, ARG_SLABS), dim3(256), 0, st, avg, up, part);
+    hipLaunchKernelGGL(argmax_kernel, dim3(NJ, ARG_SLABS, ARG_XBLOCKS), dim3(128), 0, st, avg, up, part);
     return hipGetLastError();
 }
 
@@ -278,11 +287,12 @@ __global__ __launch_bounds__(64) void joints_kernel(const ArgPartial* __restrict
     float p3[3] = {0.f, 0.f, 0.f};
     double row = 0, col = 0;
     if (live) {
-        double bv = part[j * ARG_SLABS].v;
-        int bi = part[j * ARG_SLABS].idx;
-        for (int s = 1; s < ARG_SLABS; s++) {
-            const double v = part[j * ARG_SLABS + s].v;
-            const int i = part[j * ARG_SLABS + s].idx;
+        constexpr int NP = ARG_SLABS * ARG_XBLOCKS;
+        double bv = part[j * NP].v;
+        int bi = part[j * NP].idx;
+        for (int s = 1; s < NP; s++) {
+            const double v = part[j * NP + s].v;
+            const int i = part[j * NP + s].idx;
             if (better(v, i, bv, bi)) bv = v, bi = i;
         }
         if (bi == 0x7fffffff) bi = 0;  // all-NaN map: np.argmax would return the first NaN; documented deviation
