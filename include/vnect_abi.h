@@ -114,14 +114,15 @@ int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t
 
 typedef struct vnect_timings {
     int32_t struct_size;
-    int32_t frames;            /* frames since the last vnect_reset_timings                     */
-    double total_ms;           /* HIP-event time, first kernel .. last kernel of each frame      */
-    double net_ms;             /* of which the conv stack (a1-a7)                                 */
-    double pre_ms, post_ms;    /* input pyramid; merge + joints                                   */
-    int32_t conv_launches;     /* conv-type kernel launches per frame                             */
-    double conv_flops;         /* algorithmic conv FLOPs per frame (2*MAC, live graph)            */
+    int32_t frames;            /* profiled frames since the last vnect_reset_timings                              */
+    double total_ms;           /* HIP events around the whole frame (pre + conv stack + post), summed over frames  */
+    double net_ms;             /* first conv kernel start .. last conv kernel end (device clock), summed           */
+    double conv_ms;            /* sum of the conv kernels' own durations (device clock, like rocprofv3), summed    */
+    int32_t conv_launches;     /* conv kernel launches per frame                                                   */
+    double conv_flops;         /* algorithmic conv FLOPs per frame (2*MAC, live graph)                             */
 } vnect_timings;
-/* Event timing is collected only on the non-graph path (use_graph=0) or when profiling is on. */
+/* Profiling replays a twin of the frame graph in which every conv kernel stamps its start and end with the
+ * 100 MHz device clock (s_memrealtime); off by default, no cost when off. */
 int vnect_set_profiling(vnect_handle* h, int on);
 int vnect_get_timings(vnect_handle* h, vnect_timings* out);
 int vnect_reset_timings(vnect_handle* h);
@@ -133,7 +134,7 @@ typedef struct vnect_layer_info {
     int32_t M, N, K;           /* implicit-GEMM view                                              */
     int32_t tile_m, tile_n, split_k, workgroups;
     double flops;              /* algorithmic                                                     */
-    double last_ms;            /* HIP-event time of the last profiled run (0 if none)             */
+    double last_ms;            /* kernel duration in the last profiled frame, device clock (0 if none) */
 } vnect_layer_info;
 int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out);
 

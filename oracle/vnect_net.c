@@ -131,11 +131,16 @@ static void gemm_gather(const gather_t* g, int M, int N, int K, const float* B, 
                 }
             }
             float* Ap = Apool + (size_t)omp_get_thread_num() * MC * KC;
+            /* 2-D decomposition (row block x group of column panels) so that small-M layers still give every
+             * thread work; K is never split, so results do not depend on the thread count. */
+            const int NG = 4; /* column panels per task */
+            const int ngrp = (npan + NG - 1) / NG, nblk = (M + MC - 1) / MC;
 #pragma omp for schedule(dynamic, 1)
-            for (int ic = 0; ic < M; ic += MC) {
+            for (int task = 0; task < nblk * ngrp; task++) {
+                const int ic = (task / ngrp) * MC, jg = task % ngrp;
                 int mc = M - ic < MC ? M - ic : MC;
                 pack_a(g, ic, mc, pc, kc, M, Ap);
-                for (int jp = 0; jp < npan; jp++) {
+                for (int jp = jg * NG; jp < npan && jp < (jg + 1) * NG; jp++) {
                     int nr = N - jp * NR < NR ? N - jp * NR : NR;
                     for (int ip = 0; ip * MR < mc; ip++) {
                         int mr = mc - ip * MR < MR ? mc - ip * MR : MR;

@@ -6,7 +6,7 @@ from tests import helpers
 from vnect_amd import _native
 from vnect_amd.weights import synthetic_weights
 
-h = _native.Handle([1.0, 0.8, 0.6], use_graph=False)
+h = _native.Handle([1.0, 0.8, 0.6])
 h.set_weights(synthetic_weights()); h.finalize()
 h.upload_frame(0, helpers.synth_frame(1234))
 for i in range(5):

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 output of tools/profile_round.sh into small files for profiles/.
+
+Writes <out>/summary/<round>_kernel_stats.csv (rocprofv3's own --stats table), <round>_conv_roofline.json and
+<round>_traffic.json.  HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE is reported in KiB-like units of 1 KB and
+counts 64 B per 128-B request on gfx950 for wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, rnd = sys.argv[1], sys.argv[2]
+sumdir = os.path.join(out, "summary")
+os.makedirs(sumdir, exist_ok=True)
+FLOPS_PER_FRAME = 71.49e9
+
+
+def find(sub, pat):
+    g = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return g[0] if g else None
+
+
+res = {}
+st = find("stats", "*kernel_stats.csv")
+if st:
+    rows = list(csv.DictReader(open(st)))
+    with open(os.path.join(sumdir, rnd + "_kernel_stats.csv"), "w") as f:
+        f.write(open(st).read())
+    conv = [r for r in rows if "conv_f32" in r["Name"]]
+    calls = sum(int(r["Calls"]) for r in conv)
+    tot_ns = sum(float(r["TotalDurationNs"]) for r in conv)
+    allk = sum(float(r["TotalDurationNs"]) for r in rows)
+    sq = [r for r in rows if "squarify" in r["Name"]]
+    frames = int(sq[0]["Calls"]) if sq else 0
+    res["frames_profiled"] = frames
+    res["conv_kernel"] = conv[0]["Name"] if conv else None
+    res["conv_calls_per_frame"] = calls / max(frames, 1)
+    res["conv_avg_us_per_launch"] = tot_ns / max(calls, 1) / 1e3
+    res["conv_ms_per_frame"] = tot_ns / max(frames, 1) / 1e6
+    res["all_kernels_ms_per_frame"] = allk / max(frames, 1) / 1e6
+    res["conv_tflops"] = FLOPS_PER_FRAME / (tot_ns / max(frames, 1) * 1e-9) / 1e12
+    res["conv_frac_of_fp32_mfma_peak"] = res["conv_tflops"] / 157.3
+
+
+def counter_sum(sub, name):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        return None, 0
+    tot, n = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != name:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        tot[k] += float(r["Counter_Value"])
+        n[k] += 1
+    return tot, n
+
+
+ft, fn = counter_sum("fetch", "FETCH_SIZE")
+wt, wn = counter_sum("write", "WRITE_SIZE")
+if ft and wt and res.get("frames_profiled"):
+    fr = res["frames_profiled"]
+    per_kernel = {}
+    for k in sorted(set(ft) | set(wt)):
+        per_kernel[k] = {"fetch_KB_raw_per_frame": ft.get(k, 0) / fr, "write_KB_per_frame": wt.get(k, 0) / fr}
+    conv_f = sum(v for k, v in ft.items() if "conv_f32" in k) / fr
+    conv_w = sum(v for k, v in wt.items() if "conv_f32" in k) / fr
+    traffic = {
+        "note": "per frame, conv_f32 kernels only; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request), WRITE_SIZE as is; units KB=1024 B",
+        "fetch_bytes_per_frame": conv_f * 2 * 1024, "write_bytes_per_frame": conv_w * 1024,
+        "hbm_bytes_per_frame": (conv_f * 2 + conv_w) * 1024, "per_kernel": per_kernel}
+    json.dump(traffic, open(os.path.join(sumdir, rnd + "_traffic.json"), "w"), indent=1)
+    res["conv_hbm_bytes_per_frame"] = traffic["hbm_bytes_per_frame"]
+for tag in ("stats", "fetch", "write"):
+    b = os.path.join(out, "bench_%s.json" % tag)
+    if os.path.exists(b) and os.path.getsize(b):
+        try:
+            res["bench_under_" + tag] = json.loads(open(b).read().strip().splitlines()[-1])
+        except Exception as e:  # noqa
+            res["bench_under_" + tag] = "unparsed: %s" % e
+json.dump(res, open(os.path.join(sumdir, rnd + "_conv_roofline.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if not k.startswith("bench_")}, indent=1))

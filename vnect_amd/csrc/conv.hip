@@ -52,6 +52,9 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const bool producer = threadIdx.x >= 256;
     const int wm = wave >> 1, wn = wave & 1;
+    // profiling twin only: the first 8 workgroups (first dispatched) stamp the start, every workgroup its end
+    // into one of 8 slots (one address would serialise ~1600 atomics)
+    if (a.prof && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(a.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     // XCD-aware tile order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs,
     // so give every XCD a contiguous run of the logical tile sequence (N-tile fastest, then M, then K-slice /
     // phase): tiles that share an activation row block, and all weight tiles, then meet in one XCD's L2.
@@ -304,6 +307,10 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
                 }
             }
         }
+    }
+    if (a.prof && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+        atomicMax(a.prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 

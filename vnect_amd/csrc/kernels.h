@@ -12,6 +12,7 @@ constexpr int MAPC = 84;       // 4 maps x 21 joints
 constexpr int ARG_SLABS = 8;   // row slabs per joint in the arg-max kernel (368 / 8 = 46 rows each)
 constexpr int ARG_XBLOCKS = 3; // 128-column blocks per slab
 constexpr int MAX_TAPS = 16;
+constexpr int PROF_SLOTS = 16;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
 //   m = (s*Ho + oy)*Wo + ox, k = (tap, ci), A[m][k] = in[s][oy*stride + dy[tap]][ox*stride + dx[tap]][ci]
@@ -24,6 +25,7 @@ struct ConvArgs {
     const float* resid;   // nullptr or same pixel indexing as out
     float* out;
     float* ws;            // split-K workspace [ksplit][out pixels][Npad]
+    unsigned long long* prof;  // nullptr, or {min start, 8 x max end} of this launch in 100 MHz s_memrealtime ticks
     const float* zeros;   // >= 128 B of zeros (source of padded taps / rows past M for the LDS-DMA loads)
     int S, H, W, Cs;      // input grid, floats per input pixel
     int Ho, Wo, M;        // logical output grid, M = S*Ho*Wo

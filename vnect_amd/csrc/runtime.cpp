@@ -45,7 +45,6 @@ struct Layer {
     int Nreal = 0, Kreal = 0;
     double flops = 0;
     float last_ms = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
 constexpr int RING = 4;
@@ -93,6 +92,11 @@ struct vnect_handle {
     // graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
+    hipGraph_t pgraph = nullptr;  // profiling twin: same launches, every conv kernel stamps its start/end
+    hipGraphExec_t pgexec = nullptr;
+    unsigned long long* d_prof = nullptr;       // [layer][2] device stamps (100 MHz)
+    unsigned long long* h_prof = nullptr;       // pinned read-back
+    unsigned long long* h_prof_init = nullptr;  // pinned {~0, 0} pattern
     // profiling
     bool profiling = false;
     hipEvent_t ev[4] = {};
@@ -614,14 +618,10 @@ int finalize_impl(vnect_handle* h)
 int run_network(vnect_handle* h, bool timed)
 {
     for (Layer& L : h->layers) {
-        if (timed) {
-            if (!L.e0) HIPCK(h, hipEventCreate(&L.e0));
-            if (!L.e1) HIPCK(h, hipEventCreate(&L.e1));
-            HIPCK(h, hipEventRecord(L.e0, h->st));
-        }
         if (L.op == OP_CONV) {
-            static const int repeat = getenv("VNECT_REPEAT") ? atoi(getenv("VNECT_REPEAT")) : 1;  // tuning: warm-L2 reruns
-            for (int rep = 0; rep < repeat; rep++) HIPCK(h, launch_conv(L.a, L.BM, L.BN, h->st));
+            ConvArgs a = L.a;
+            a.prof = timed ? h->d_prof + PROF_SLOTS * (&L - h->layers.data()) : nullptr;
+            HIPCK(h, launch_conv(a, L.BM, L.BN, h->st));
             if (L.a.ksplit > 1) HIPCK(h, launch_reduce(L.r, h->st));
         } else if (L.op == OP_POOL) {
             const Tensor &i = h->tensors[L.in], &o = h->tensors[L.out];
@@ -630,7 +630,6 @@ int run_network(vnect_handle* h, bool timed)
             const Tensor& t = h->tensors[L.out];
             HIPCK(h, launch_bone(t.d, (long long)t.S * t.H * t.W, t.Cs, h->st));
         }
-        if (timed) HIPCK(h, hipEventRecord(L.e1, h->st));
     }
     return VNECT_OK;
 }
@@ -681,21 +680,40 @@ int reset_filters_impl(vnect_handle* h)
     return VNECT_OK;
 }
 
+int run_frame_kernels(vnect_handle* h, bool timed)
+{
+    const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
+    if (timed) HIPCK(h, hipMemcpyAsync(h->d_prof, h->h_prof_init, pbytes, hipMemcpyHostToDevice, h->st));
+    int rc = run_pre(h);
+    if (rc) return rc;
+    rc = run_network(h, timed);
+    if (rc) return rc;
+    rc = run_post(h);
+    if (rc) return rc;
+    if (timed) HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
+    return VNECT_OK;
+}
+
 int build_graph(vnect_handle* h)
 {
-    if (h->gexec) {
-        hipGraphExecDestroy(h->gexec), h->gexec = nullptr;
-        hipGraphDestroy(h->graph), h->graph = nullptr;
-    }
+    if (h->gexec) hipGraphExecDestroy(h->gexec), h->gexec = nullptr;
+    if (h->graph) hipGraphDestroy(h->graph), h->graph = nullptr;
+    if (h->pgexec) hipGraphExecDestroy(h->pgexec), h->pgexec = nullptr;
+    if (h->pgraph) hipGraphDestroy(h->pgraph), h->pgraph = nullptr;
     if (!h->cfg.use_graph) return VNECT_OK;
     HIPCK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
-    int rc = run_pre(h);
-    if (!rc) rc = run_network(h, false);
-    if (!rc) rc = run_post(h);
+    int rc = run_frame_kernels(h, false);
     hipError_t e = hipStreamEndCapture(h->st, &h->graph);
     if (rc) return rc;
     HIPCK(h, e);
     HIPCK(h, hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+    // profiling twin: identical launches, but every conv kernel stamps {min start, max end} (s_memrealtime)
+    HIPCK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+    rc = run_frame_kernels(h, true);
+    e = hipStreamEndCapture(h->st, &h->pgraph);
+    if (rc) return rc;
+    HIPCK(h, e);
+    HIPCK(h, hipGraphInstantiate(&h->pgexec, h->pgraph, nullptr, nullptr, 0));
     return VNECT_OK;
 }
 
@@ -720,15 +738,13 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     const bool timed = h->profiling;
     if (h->gexec && !timed) {
         HIPCK(h, hipGraphLaunch(h->gexec, h->st));
+    } else if (h->pgexec && timed) {
+        HIPCK(h, hipEventRecord(h->ev[0], h->st));
+        HIPCK(h, hipGraphLaunch(h->pgexec, h->st));
+        HIPCK(h, hipEventRecord(h->ev[3], h->st));
     } else {
         if (timed) HIPCK(h, hipEventRecord(h->ev[0], h->st));
-        rc = run_pre(h);
-        if (rc) return rc;
-        if (timed) HIPCK(h, hipEventRecord(h->ev[1], h->st));
-        rc = run_network(h, timed);
-        if (rc) return rc;
-        if (timed) HIPCK(h, hipEventRecord(h->ev[2], h->st));
-        rc = run_post(h);
+        rc = run_frame_kernels(h, timed);
         if (rc) return rc;
         if (timed) HIPCK(h, hipEventRecord(h->ev[3], h->st));
     }
@@ -748,13 +764,26 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
     if (j2) memcpy(j2, h->h_out[ring]->j2d, sizeof(double) * NJ * 2);
     if (j3) memcpy(j3, h->h_out[ring]->j3d, sizeof(float) * NJ * 3);
     if (h->profiling) {
-        float a = 0, b = 0, c = 0;
-        hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
-        hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-        hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
-        h->tim.frames++, h->tim.pre_ms += a, h->tim.net_ms += b, h->tim.post_ms += c, h->tim.total_ms += a + b + c;
-        for (Layer& L : h->layers)
-            if (L.e0 && L.e1) hipEventElapsedTime(&L.last_ms, L.e0, L.e1);
+        float frame_ms = 0;
+        hipEventElapsedTime(&frame_ms, h->ev[0], h->ev[3]);
+        unsigned long long first = ~0ull, last = 0;
+        double conv_ms = 0;
+        for (size_t i = 0; i < h->layers.size(); i++) {
+            Layer& L = h->layers[i];
+            const unsigned long long* p = h->h_prof + PROF_SLOTS * i;
+            const unsigned long long t0 = p[0];
+            unsigned long long t1 = 0;
+            for (int k = 1; k <= 8; k++) t1 = std::max(t1, p[k]);
+            L.last_ms = 0;
+            if (L.op != OP_CONV || t1 <= t0) continue;
+            L.last_ms = (float)((double)(t1 - t0) * 1e-5);  // 100 MHz ticks -> ms
+            conv_ms += L.last_ms;
+            first = std::min(first, t0), last = std::max(last, t1);
+        }
+        h->tim.frames++;
+        h->tim.total_ms += frame_ms;                                     // HIP events around the whole frame
+        h->tim.net_ms += last > first ? (double)(last - first) * 1e-5 : 0;  // first conv start .. last conv end
+        h->tim.conv_ms += conv_ms;                                       // sum of conv kernel durations
     }
     return VNECT_OK;
 }
@@ -823,6 +852,10 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         HIPCK(h, hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming));
     }
     for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
+    if ((rc = dev_alloc(h, &h->d_prof, PROF_SLOTS * 128))) return rc;
+    HIPCK(h, hipHostMalloc((void**)&h->h_prof, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void**)&h->h_prof_init, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
+    for (int i = 0; i < PROF_SLOTS * 128; i++) h->h_prof_init[i] = (i % PROF_SLOTS) == 0 ? ~0ull : 0, h->h_prof[i] = 0;
     if ((rc = build_scale_tables(h))) return rc;
     if ((rc = build_up_table(h))) return rc;
     if ((rc = reset_filters_impl(h))) return rc;
@@ -837,10 +870,8 @@ void vnect_destroy(vnect_handle* h)
     if (h->st) hipStreamSynchronize(h->st);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     if (h->graph) hipGraphDestroy(h->graph);
-    for (Layer& L : h->layers) {
-        if (L.e0) hipEventDestroy(L.e0);
-        if (L.e1) hipEventDestroy(L.e1);
-    }
+    if (h->pgexec) hipGraphExecDestroy(h->pgexec);
+    if (h->pgraph) hipGraphDestroy(h->pgraph);
     for (int i = 0; i < RING; i++) {
         if (h->h_fp[i]) hipHostFree(h->h_fp[i]);
         if (h->h_out[i]) hipHostFree(h->h_out[i]);
@@ -848,6 +879,8 @@ void vnect_destroy(vnect_handle* h)
     }
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
+    if (h->h_prof) hipHostFree(h->h_prof);
+    if (h->h_prof_init) hipHostFree(h->h_prof_init);
     for (void* p : h->dev_allocs) hipFree(p);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
@@ -915,14 +948,11 @@ int vnect_forward(vnect_handle* h, const float* batch, int num_images, float* ou
     const long long npix = (long long)h->S * BOX * BOX;
     HIPCK(h, hipMemcpyAsync(h->in3, batch, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->st));
     HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->st));
-    int rc = run_network(h, h->profiling);
+    int rc = run_network(h, false);
     if (rc) return rc;
     const Tensor& t = h->tensors[h->t_out];
     HIPCK(h, hipMemcpyAsync(out, t.d, t.floats() * sizeof(float), hipMemcpyDeviceToHost, h->st));
     HIPCK(h, hipStreamSynchronize(h->st));
-    if (h->profiling)
-        for (Layer& L : h->layers)
-            if (L.e0 && L.e1) hipEventElapsedTime(&L.last_ms, L.e0, L.e1);
     return VNECT_OK;
 }
 
