@@ -199,6 +199,10 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
 
     if (producer) {
         // ---- producer waves: keep NS-1 chunks in flight, publish chunk t+1 at barrier t --------------------
+        // With MFMAs running, a CU retires only ~one LDS-DMA instruction per 70 cycles (tools/mfma_lds.hip): the
+        // producers, not the MFMA chain, pace a 64x64 tile.  They get issue priority; the dependent MFMA chain only
+        // needs one issue slot per 64 cycles.
+        __builtin_amdgcn_s_setprio(3);
         set_tap(tap);
 #pragma unroll
         for (int p = 0; p < NS - 1; p++)
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
         wait_landed(total - 1 < NS - 2 ? total - 1 : NS - 2);
         __builtin_amdgcn_s_barrier();  // chunk 0 visible
         int stage = 0;
-        for (int t = 0; t + 1 < total; t++) {
+        for (int t = 0; t < total; t++) {  // one barrier per chunk, also after the last one (keeps the consumer loop branch-free)
             // chunk t+1 complete in LDS; younger chunks still in flight: t+2 .. min(t+NS-2, total-1)
             const int young = total - 2 - t;
             wait_landed(young < NS - 3 ? young : NS - 3);
@@ -230,17 +234,36 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
         for (int q = 0; q < 4; q++) rfrag(stg, q, F.a[q], F.b[q]);
     };
     int stage = 0;
+    // One chunk = 16 MFMAs per accumulator.  The reads of chunk t+1 are issued ONE PER MFMA behind the barrier:
+    // a wave issues in order, and eight back-to-back ds_read_b128 hold its issue slot for ~35 cycles each when
+    // four waves read at once (tools/lds_read.hip) -- behind an MFMA that time is free, in a burst it is not.
     auto step = [&](Frag& cur, Frag& nxt, int t) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
         mma(cur.a[0], cur.b[0]);
         mma(cur.a[1], cur.b[1]);
-        if (t + 1 < total) {
-            __builtin_amdgcn_s_barrier();  // chunk t+1 visible; every consumer is past chunk t-1
+        // after the last chunk the barrier and the reads still run (the reads fetch stale ring data that is never
+        // used): no branch sits between the MFMAs
+        __builtin_amdgcn_s_barrier();  // chunk t+1 visible; every consumer is past chunk t-1
+        if constexpr (TM == 1 && TN == 1) {
+            const float* Ab = smem + nstage * STAGE + (wm * WM) * 32;
+            const float* Bb = smem + nstage * STAGE + (BM + wn * WN) * 32;
+#pragma unroll
+            for (int q = 2; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][0][e], cur.b[q][0][e], acc[0][0], 0, 0, 0);
+                    const int r = (q - 2) * 4 + e;  // 0..7: fragment r>>1 of A (even r) or B (odd r)
+                    if (r & 1) nxt.b[r >> 1][0] = *(const f32x4*)(Bb + fo[r >> 1]);
+                    else nxt.a[r >> 1][0] = *(const f32x4*)(Ab + fo[r >> 1]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one DS read
+                }
+        } else {
             rall(nstage, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur.a[2], cur.b[2]);
+            mma(cur.a[3], cur.b[3]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mma(cur.a[2], cur.b[2]);
-        mma(cur.a[3], cur.b[3]);
         __builtin_amdgcn_sched_barrier(0);
         stage = nstage;
     };
