@@ -269,3 +269,32 @@ def test_errors_mirror_reference(weights):
     j2, j3 = est(frame, timestamp=7.0)
     assert np.all(np.isfinite(j2))
     est.close()
+
+
+def test_tracking_loop_variable_crops(weights, oracle_net):
+    """run_estimator_ps.py:80-109 headless: the crop changes every frame, so squarify/resize tables are rebuilt per
+    call; every frame is checked against the oracle fed the same crop (2-D by the tie rule, 3-D by tolerance)."""
+    import oracle
+    from vnect_amd import VNectEstimator, runner
+    scales = [1.0, 0.8, 0.6]
+    est = VNectEstimator(scales=scales, weights=weights, verbose=False)
+    ref = oracle.OracleEstimator(scales=scales, net=oracle_net)
+    frames = list(runner.synthetic_stream(3, 4, 480, 640))
+    rect, sizes = [40, 30, 500, 400], set()
+    for k, frame in enumerate(frames):
+        x, y, w, h = rect
+        crop = frame[y:y + h, x:x + w, :]
+        sizes.add(crop.shape)
+        t = T0 + k / 30
+        j2, j3 = est(crop, timestamp=(t, t + 0.001))
+        r2, r3 = ref(np.ascontiguousarray(crop), t, t + 0.001)
+        same = np.all(np.abs(j2 - r2) <= 1e-6, axis=1)
+        assert same.mean() >= 0.8, (k, int(same.sum()))
+        assert np.all(np.abs(j3 - r3)[same] <= 0.05 + 1e-4 * np.abs(r3)[same]), k
+        j2[:, 0] += y
+        j2[:, 1] += x
+        rect = runner.bbox_update(j2, 640, 480)
+        if rect[2] < 8 or rect[3] < 8:
+            rect = [0, 0, 640, 480]
+    assert len(sizes) >= 2   # the loop really exercised more than one crop geometry
+    est.close()
