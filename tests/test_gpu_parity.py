@@ -62,7 +62,10 @@ def test_conv_stack_every_layer(h3, oracle_net):
     names = [L["name"] for L in h3.layers()]
     acts = ["conv1", "pool1"]
     for n in names:
-        if n == "res5c_branch2c":
+        if "+" in n:                          # two layers in one launch: "<scope_a>+<rest of scope_b>"
+            a, b = n.split("+")
+            acts += [a, a.split("_")[0] + "_" + b]
+        elif n == "res5c_branch2c":
             acts.append(n)
         elif n.endswith("_branch2c") or n == "res5a_branch2c_new":
             acts.append(n.split("_")[0])      # block output resNx

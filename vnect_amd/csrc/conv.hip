@@ -281,8 +281,11 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
     const int py = phase >> 1, px = phase & 1;
     const bool direct = (a.os == 1);
     const long long npix = (long long)a.S * a.OH * a.OW;
-    float* __restrict__ outp = fused ? a.out : a.ws + (long long)ks * npix * a.Npad;
-    const int ldo = fused ? a.ldc : a.Npad;
+    // Two layers that read the same input run as one GEMM (columns [0, split_n) -> out, the rest -> out2): the whole
+    // 64-wide tile lies on one side because split_n is a multiple of the tile width.
+    const bool second = fused && a.out2 != nullptr && n0 >= a.split_n;
+    float* __restrict__ outp = !fused ? a.ws + (long long)ks * npix * a.Npad : (second ? a.out2 - a.split_n : a.out);
+    const int ldo = !fused ? a.Npad : (second ? a.ldc2 : a.ldc);
     float* scr = smem + wave * (32 * LDT);
 #pragma unroll
     for (int j = 0; j < TN; j++) {

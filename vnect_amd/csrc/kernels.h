@@ -24,6 +24,7 @@ struct ConvArgs {
     const float* shift;
     const float* resid;   // nullptr or same pixel indexing as out
     float* out;
+    float* out2;          // second output tensor for columns >= split_n (two layers sharing one input), or nullptr
     float* ws;            // split-K workspace [ksplit][out pixels][Npad]
     unsigned long long* prof;  // nullptr, or {min start, 8 x max end} of this launch in 100 MHz s_memrealtime ticks
     const float* zeros;   // >= 128 B of zeros (source of padded taps / rows past M for the LDS-DMA loads)
@@ -33,6 +34,7 @@ struct ConvArgs {
     int stride;
     int Npad, Nvalid;
     int ldc, ldr;         // floats per out / resid pixel
+    int ldc2, split_n;    // out2 pixel stride; first column of out2 (multiple of the tile width)
     int OH, OW, os;       // out pixel = (s, oy*os + py, ox*os + px) in an (OH, OW) grid
     int nphase;           // 1, or 4 for the transposed conv (py = phase>>1, px = phase&1)
     int ksplit;

@@ -37,7 +37,7 @@ enum OpKind { OP_CONV, OP_POOL, OP_BONE };
 struct Layer {
     OpKind op = OP_CONV;
     std::string name;
-    int in = -1, resid = -1, out = -1;
+    int in = -1, resid = -1, out = -1, out2 = -1;
     ConvArgs a{};
     ReduceArgs r{};
     int BM = 64, BN = 64;
@@ -410,6 +410,54 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     return L.out;
 }
 
+// Two 1x1 convs of one input with one stride (branch2a with ReLU, branch1 without; vnect_model.py:32-35,64-67,
+// 106-109,168-175) as ONE launch: weights concatenated along N ([branch2a | branch1]), ReLU on the first block of
+// columns only, two output tensors.  Returns the branch2a tensor, *shortcut gets the branch1 tensor.
+int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std::string& sb, int cout_b, int in,
+                  int stride, int* shortcut)
+{
+    const Tensor tin = h->tensors[in];
+    const int cin = tin.C;
+    const HostArray* Wa = get_w(h, sa + "/weights", {1, 1, cin, cout_a});
+    const HostArray* Ba = Wa ? get_w(h, sa + "/biases", {cout_a}) : nullptr;
+    const HostArray* Wb = Ba ? get_w(h, sb + "/weights", {1, 1, cin, cout_b}) : nullptr;
+    const HostArray* Bb = Wb ? get_w(h, sb + "/biases", {cout_b}) : nullptr;
+    if (!Bb) return -1;
+    if (cout_a % 64 || tin.Cs % 32) {
+        h->err = "internal: paired conv needs 64-aligned split";
+        return -1;
+    }
+    const int ho = (tin.H - 1) / stride + 1, wo = (tin.W - 1) / stride + 1;
+    Layer L;
+    L.op = OP_CONV, L.name = sa + "+" + sb.substr(sb.find('_') + 1), L.in = in;
+    L.out = add_tensor(h, sa, tin.S, ho, wo, cout_a, cout_a);
+    L.out2 = add_tensor(h, sb, tin.S, ho, wo, cout_b, cout_b);
+    ConvArgs& a = L.a;
+    a.S = tin.S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
+    a.Ho = ho, a.Wo = wo, a.M = tin.S * ho * wo, a.stride = stride;
+    a.OH = ho, a.OW = wo, a.os = 1, a.nphase = 1;
+    a.ldc = cout_a, a.ldc2 = cout_b, a.split_n = cout_a, a.ldr = 0;
+    a.relu_cols = cout_a;
+    a.ntaps = 1, a.cpt = tin.Cs / 32, a.K = tin.Cs;
+    L.Nreal = cout_a + cout_b, L.Kreal = cin;
+    a.Nvalid = L.Nreal;
+    L.flops = 2.0 * a.M * (double)cin * L.Nreal;
+    choose_tile(L, (long long)a.M);
+    if (L.BN != 64 || L.a.ksplit != 1) L.BM = 64, L.BN = 64, L.a.ksplit = 1;  // the column split relies on 64-wide tiles, no slabs
+    a.Npad = round_up(L.Nreal, 64);
+    std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
+    for (int ci = 0; ci < cin; ci++) {
+        for (int n = 0; n < cout_a; n++) wp[(size_t)n * a.K + ci] = Wa->d[(size_t)ci * cout_a + n];
+        for (int n = 0; n < cout_b; n++) wp[(size_t)(cout_a + n) * a.K + ci] = Wb->d[(size_t)ci * cout_b + n];
+    }
+    for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
+    for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
+    if (upload(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
+    h->layers.push_back(L);
+    *shortcut = L.out2;
+    return L.out;
+}
+
 int finalize_impl(vnect_handle* h)
 {
     const int S = h->S;
@@ -441,8 +489,8 @@ int finalize_impl(vnect_handle* h)
     }
     // bottleneck blocks (vnect_model.py:31-165); block output tensors are named resNx
     auto proj = [&](const std::string& p, int x, int mid, int out, int stride) {
-        int s = conv(p + "_branch1", x, 1, stride, out, false);
-        int a = s < 0 ? -1 : conv(p + "_branch2a", x, 1, stride, mid, true);
+        int s = -1;
+        int a = add_conv_pair(h, p + "_branch2a", mid, p + "_branch1", out, x, stride, &s);
         int b = a < 0 ? -1 : conv(p + "_branch2b", a, 3, 1, mid, true);
         return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, s, p);
     };
@@ -485,12 +533,11 @@ int finalize_impl(vnect_handle* h)
     }
     // res5a / res5b (vnect_model.py:167-185)
     {
-        int a = conv("res5a_branch2a_new", r, 1, 1, 512, true);
+        int s = -1;
+        int a = add_conv_pair(h, "res5a_branch2a_new", 512, "res5a_branch1_new", 1024, r, 1, &s);
         NEED(a);
         int b = conv("res5a_branch2b_new", a, 3, 1, 512, true);
         NEED(b);
-        int s = conv("res5a_branch1_new", r, 1, 1, 1024, false);
-        NEED(s);
         r = conv("res5a_branch2c_new", b, 1, 1, 1024, true, s, "res5a");
         NEED(r);
         a = conv("res5b_branch2a_new", r, 1, 1, 256, true);
@@ -600,6 +647,7 @@ int finalize_impl(vnect_handle* h)
         if (L.op != OP_CONV) continue;
         ConvArgs& a = L.a;
         a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
+        a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
         a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
         a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws, a.zeros = h->zeros;
         if (a.ksplit > 1) {
