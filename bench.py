@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pyramid", action="store_true",
+                    help="BASELINE.json configs[3]: ONE stream, one scale per GPU (needs --gpus 3), RCCL all-gather of the "
+                         "maps; default for N>1 is N independent streams (configs[4])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,13 +74,24 @@ def main():
     rank, local_rank = grp.rank, grp.local_rank
 
     weights = synthetic_weights()
-    h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8)
+    if args.pyramid:
+        if args.gpus != len(SCALES):
+            sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
+        h = _native.Handle(SCALES, device=local_rank, num_frame_slots=8, pyramid=(rank, world))
+    else:
+        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8)
     h.set_weights(weights)
     h.finalize()
-    # one synthetic video stream per rank: seeds 1234 + 1000*stream
+    if args.pyramid:  # rank 0 makes the ncclUniqueId, torch.distributed carries it to the others
+        import torch.distributed as dist
+        uid = [_native.Handle.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(rank, world, uid[0])
+    # replicas: one synthetic video stream per rank, seeds 1234 + 1000*stream;
+    # pyramid: every rank sees the SAME stream 0
     nslots = 8
     for k in range(nslots):
-        h.upload_frame(k, helpers.synth_frame(stream_seed(rank, k)))
+        h.upload_frame(k, helpers.synth_frame(stream_seed(0 if args.pyramid else rank, k)))
 
     t = 1.7e9
     for i in range(args.warmup):
@@ -108,10 +122,12 @@ def main():
     h.collect()
     torch.cuda.synchronize()
     pipelined = args.steps / (time.perf_counter() - p0)
+    t += 1 + args.steps / 30 + 1
 
     out = None
-    if rank == 0:
-        # Dominant kernel = vnect::conv_f32_glds_kernel<64,64,5> (52 launches per frame, the whole conv stack).
+    tim = None
+    if rank == 0 or args.pyramid:  # pyramid: every inference is collective, so every rank must take part
+        # Dominant kernel = vnect::conv_f32_glds_kernel<64,64,5> (the whole conv stack).
         # Its launch durations are taken live from a profiling twin of the frame graph in which every conv
         # kernel stamps its first-wave start and last-wave end with the 100 MHz device clock (what rocprofv3's
         # kernel trace reports); HIP events on the library's stream bracket the whole replayed frame.
@@ -123,8 +139,9 @@ def main():
             h.infer_resident(i % nslots, t + 10, t + 10 + 1e-3)
         tim = h.timings()
         h.set_profiling(False)
+    if rank == 0:
         conv_ms = tim["conv_ms"] / nprof
-        achieved = FLOPS_PER_FRAME / (conv_ms * 1e-3) / 1e12
+        achieved = FLOPS_PER_FRAME / (len(SCALES) if args.pyramid else 1) / (conv_ms * 1e-3) / 1e12  # per GPU
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
@@ -132,14 +149,15 @@ def main():
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": "frames/sec, 368x368 3-scale VNect inference",
-            "value": round(aggregate_rate(args.gpus, args.steps, elapsed), 2),
+            "value": round(aggregate_rate(1 if args.pyramid else args.gpus, args.steps, elapsed), 2),
             "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if args.pyramid else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "368x368x3 uint8 BGR frame -> 21 joints; scales [1.0,0.8,0.6]; fp32; batch 1 "
                                    "(BASELINE.json configs[1]); N>1 = N independent streams, one per GPU",
                        "weights": "seeded synthetic (reference ships none)", "frames_resident_in_hbm": True,
-                       "hip_graph": not args.no_graph, "sync_per_frame": True},
+                       "hip_graph": not args.no_graph and not args.pyramid, "sync_per_frame": True,
+                       "parallelism": "pyramid: 1 scale per GPU + RCCL all-gather" if args.pyramid else "stream replicas"},
             "pipelined_frames_per_s_per_gpu": round(pipelined, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,

@@ -53,6 +53,9 @@ typedef struct vnect_config {
                                          numpy TF1 runs with), 1 = NEP 50 (numpy >= 2)            */
     int32_t max_frame_bytes;          /* capacity of one resident frame slot; 0 -> 4096*4096*3     */
     int32_t num_frame_slots;          /* resident frame slots (>=1); 0 -> 4                        */
+    int32_t pyramid_nranks;           /* 0/1 = off; else must equal num_scales: this handle runs the
+                                         pre-processing and conv stack of ONE scale (see vnect_comm_init) */
+    int32_t pyramid_rank;             /* which scale (0 .. pyramid_nranks-1)                       */
 } vnect_config;
 
 /* Replaces VNectEstimator.__init__ (src/estimator.py:27-68): session + graph + 42 + 63 filters. */
@@ -138,10 +141,14 @@ typedef struct vnect_layer_info {
 } vnect_layer_info;
 int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out);
 
-/* Pyramid sharding over RCCL (one scale per rank): rank r runs the pre-processing and
- * the conv stack for scale r only, the (46,46,84) maps are all-gathered, every rank finishes
- * the post-processing.  unique_id is an ncclUniqueId (128 bytes) created by rank 0 with
- * vnect_comm_unique_id and distributed by the host (torch.distributed / MPI / files). */
+/* Pyramid sharding over RCCL (one scale per rank; BASELINE.json configs[3]).  A handle created with
+ * pyramid_nranks == num_scales runs gen_input_batch and the conv stack for scale `pyramid_rank` only (the S
+ * images of the batch are independent through the net, src/estimator.py:75-80,100-104); its (46,46,84) maps are
+ * all-gathered (ncclAllGather, 710 976 B per rank) and every rank finishes the post-processing, so every rank
+ * returns the same joints.  All ranks must be fed the same frame and timestamps.  unique_id is an ncclUniqueId
+ * (128 bytes) made by rank 0 with vnect_comm_unique_id and distributed by the host (torch.distributed / files).
+ * vnect_comm_init must be called once, after vnect_create and before the first inference.  vnect_forward on such a
+ * handle takes ONE image (its scale). */
 int vnect_comm_unique_id(void* id128);
 int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128);
 

@@ -301,3 +301,60 @@ def test_tracking_loop_variable_crops(weights, oracle_net):
             rect = [0, 0, 640, 480]
     assert len(sizes) >= 2   # the loop really exercised more than one crop geometry
     est.close()
+
+
+# ------------------------------------------------------------------------------------------ pyramid sharding
+def test_pyramid_shards_reassemble(weights, oracle_net):
+    """configs[3] without a second GPU: three rank-handles (one scale each) run their own pre-processing and conv
+    stack; stacking their maps (what ncclAllGather delivers) and post-processing equals the unsharded result."""
+    import oracle
+    from tests import helpers
+    frame = helpers.synth_frame(4242, 400, 360, smooth=True)
+    n = _native()
+    full = _handle(BASELINE_SCALES, weights)
+    fb, scaler, (ox, oy) = full.preprocess(frame)
+    fmaps = full.forward(fb)
+    ranks = [n.Handle(BASELINE_SCALES, pyramid=(r, 3)) for r in range(3)]
+    gathered = []
+    for r, h in enumerate(ranks):
+        h.set_weights(weights)
+        h.finalize()
+        b, s, off = h.preprocess(frame)
+        assert b.shape == (1, 368, 368, 3) and s == scaler and off == [ox, oy]
+        assert np.array_equal(b[0], fb[r])                      # rank r builds scale r of the pyramid, bit for bit
+        m = h.forward(b)
+        # the S images are independent through the net; a 1-image launch plan may split K differently (other
+        # summation order), so equality is to fp32 rounding, not bitwise
+        assert np.abs(m[0] - fmaps[r]).max() <= 1e-5 * np.abs(fmaps[r]).max()
+        gathered.append(m[0])
+        with pytest.raises(n.VnectError):                       # no communicator yet: inference must refuse, not hang
+            h.infer(frame, T0, T0)
+    gathered = np.stack(gathered)
+    j2, j3 = ranks[0].postprocess(gathered, T0, T0 + 0.001, scaler, ox, oy)
+    ref = oracle.OracleEstimator(scales=BASELINE_SCALES)
+    o2, o3 = ref.postprocess(gathered, T0, T0 + 0.001, scaler, ox, oy)
+    assert np.array_equal(j2, o2) and np.array_equal(j3, o3)    # a sharded rank's post-processing == oracle on the gathered maps
+    f2, f3 = full.postprocess(fmaps, T0, T0 + 0.001, scaler, ox, oy)
+    same = np.all(j2 == f2, axis=1)
+    assert same.mean() >= 0.8 and np.all(np.abs(j3 - f3)[same] <= 0.05 + 1e-4 * np.abs(f3)[same])
+    for h in ranks + [full]:
+        h.close()
+
+
+def test_pyramid_rccl_single_rank(weights):
+    """The RCCL plumbing itself (ncclCommInitRank + ncclAllGather on the handle's stream) with a 1-rank communicator:
+    a 1-scale sharded handle must return exactly what the plain 1-scale handle returns."""
+    from tests import helpers
+    n = _native()
+    frame = helpers.synth_frame(77, smooth=True)
+    plain = _handle([1.0], weights)
+    shard = n.Handle([1.0], pyramid=(0, 1))
+    shard.set_weights(weights)
+    shard.finalize()
+    shard.comm_init(0, 1, n.Handle.comm_unique_id())
+    for k in range(3):
+        t = T0 + k / 30
+        a2, a3 = plain.infer(frame, t, t + 0.001)
+        b2, b3 = shard.infer(frame, t, t + 0.001)
+        assert np.array_equal(a2, b2) and np.array_equal(a3, b3), k
+    plain.close(), shard.close()

@@ -28,7 +28,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("num_scales", C.c_int32),
                 ("scales", C.c_double * MAX_SCALES), ("precision", C.c_int32), ("paper_res2c", C.c_int32),
                 ("use_graph", C.c_int32), ("numpy_promotion", C.c_int32), ("max_frame_bytes", C.c_int32),
-                ("num_frame_slots", C.c_int32)]
+                ("num_frame_slots", C.c_int32), ("pyramid_nranks", C.c_int32), ("pyramid_rank", C.c_int32)]
 
 
 class Timings(C.Structure):
@@ -105,7 +105,7 @@ class Handle:
     """Thin RAII wrapper over vnect_handle; every method maps 1:1 to a C entry point."""
 
     def __init__(self, scales, device=0, precision=FP32, paper_res2c=False, use_graph=True, numpy_promotion=0,
-                 max_frame_bytes=0, num_frame_slots=0):
+                 max_frame_bytes=0, num_frame_slots=0, pyramid=None):
         L = lib()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -115,10 +115,13 @@ class Handle:
             cfg.scales[i] = float(s)
         cfg.precision, cfg.paper_res2c, cfg.use_graph = precision, int(paper_res2c), int(use_graph)
         cfg.numpy_promotion, cfg.max_frame_bytes, cfg.num_frame_slots = numpy_promotion, max_frame_bytes, num_frame_slots
+        if pyramid is not None:  # (rank, nranks): this handle runs one scale of the pyramid (vnect_comm_init)
+            cfg.pyramid_rank, cfg.pyramid_nranks = int(pyramid[0]), int(pyramid[1])
         h = _H()
         rc = L.vnect_create(C.byref(cfg), C.byref(h))
         self._h = h if h.value else None
         self.num_scales = len(scales)
+        self.net_images = 1 if pyramid is not None else len(scales)
         if rc:
             msg = L.vnect_last_error(self._h).decode()
             self.close()
@@ -150,16 +153,16 @@ class Handle:
 
     def forward(self, batch):
         batch = np.ascontiguousarray(batch, dtype=np.float32)
-        if batch.shape != (self.num_scales, 368, 368, 3):
-            raise ValueError("batch must be (%d,368,368,3)" % self.num_scales)
-        out = np.empty((self.num_scales, 46, 46, 84), np.float32)
-        self._ck(lib().vnect_forward(self._h, _ptr(batch, _f32p), self.num_scales, _ptr(out, _f32p)))
+        if batch.shape != (self.net_images, 368, 368, 3):
+            raise ValueError("batch must be (%d,368,368,3)" % self.net_images)
+        out = np.empty((self.net_images, 46, 46, 84), np.float32)
+        self._ck(lib().vnect_forward(self._h, _ptr(batch, _f32p), self.net_images, _ptr(out, _f32p)))
         return out
 
     def preprocess(self, img, want_batch=True):
         img = _as_frame(img)
         H, W = img.shape[:2]
-        batch = np.empty((self.num_scales, 368, 368, 3), np.float32) if want_batch else None
+        batch = np.empty((self.net_images, 368, 368, 3), np.float32) if want_batch else None
         scaler, ox, oy = C.c_double(), C.c_int32(), C.c_int32()
         self._ck(lib().vnect_preprocess(self._h, _ptr(img, _u8p), H, W, img.strides[0],
                                         _ptr(batch, _f32p) if want_batch else None, C.byref(scaler), C.byref(ox),
@@ -200,6 +203,18 @@ class Handle:
         j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
         self._ck(lib().vnect_collect(self._h, _ptr(j2, _f64p), _ptr(j3, _f32p)))
         return j2, j3
+
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * 128)()
+        rc = lib().vnect_comm_unique_id(buf)
+        if rc:
+            raise VnectError(rc, lib().vnect_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, rank, nranks, unique_id):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._ck(lib().vnect_comm_init(self._h, rank, nranks, buf))
 
     def reset_filters(self):
         self._ck(lib().vnect_reset_filters(self._h))

@@ -93,7 +93,7 @@ struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.
 };
 
 hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st);
-hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, hipStream_t st);
+hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, int scale_base, hipStream_t st);
 
 // ---- post-processing ------------------------------------------------------------------
 struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale

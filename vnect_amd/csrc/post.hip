@@ -56,9 +56,10 @@ __global__ void squarify_kernel(const FrameParams* __restrict__ fp, uint8_t* __r
 
 // utils.img_scale_padding per scale + `/255 - 0.4` (estimator.py:76-80) -> (S,368,368,4) f32, 4th = 0
 __global__ void pyramid_kernel(const uint8_t* __restrict__ sq, const ScaleTabs* __restrict__ tabs,
-                               float* __restrict__ batch4)
+                               float* __restrict__ batch4, int scale_base)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, s = blockIdx.z;
+    // image blockIdx.z of the batch is scale (scale_base + blockIdx.z): a pyramid-sharded rank builds one scale only
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, s = blockIdx.z + scale_base;
     if (x >= BOX) return;
     int v[3] = {0, 0, 0};
     if (!tabs->scaled[s]) {
@@ -77,7 +78,7 @@ __global__ void pyramid_kernel(const uint8_t* __restrict__ sq, const ScaleTabs* 
         }
     }
     f32x4 o = {tabs->lut[v[0]], tabs->lut[v[1]], tabs->lut[v[2]], 0.f};
-    *(f32x4*)(batch4 + (((long long)s * BOX + y) * BOX + x) * 4) = o;
+    *(f32x4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4) = o;
 }
 
 hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st)
@@ -85,9 +86,9 @@ hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st)
     hipLaunchKernelGGL(squarify_kernel, dim3((BOX + 127) / 128, BOX), dim3(128), 0, st, fp, sq);
     return hipGetLastError();
 }
-hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, hipStream_t st)
+hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, int scale_base, hipStream_t st)
 {
-    hipLaunchKernelGGL(pyramid_kernel, dim3((BOX + 127) / 128, BOX, S), dim3(128), 0, st, sq, tabs, batch4);
+    hipLaunchKernelGGL(pyramid_kernel, dim3((BOX + 127) / 128, BOX, S), dim3(128), 0, st, sq, tabs, batch4, scale_base);
     return hipGetLastError();
 }
 

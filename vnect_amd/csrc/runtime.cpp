@@ -53,7 +53,8 @@ constexpr int RING = 4;
 
 struct vnect_handle {
     vnect_config cfg{};
-    int S = 0;
+    int S = 0;      // scales of the pyramid (merge, tables)
+    int Snet = 0;   // images this handle pushes through the conv stack: S, or 1 when pyramid-sharded
     std::string err;
     bool finalized = false;
     hipStream_t st = nullptr;
@@ -105,8 +106,8 @@ struct vnect_handle {
     int conv_launches = 0;
     // comm
     void* comm = nullptr;
-    int rank = 0, nranks = 1;
-    float* gather = nullptr;
+    bool sharded = false;
+    float* gather = nullptr;  // (S,46,46,84): all ranks' maps
 };
 
 namespace {
@@ -460,7 +461,7 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
 
 int finalize_impl(vnect_handle* h)
 {
-    const int S = h->S;
+    const int S = h->Snet;
     h->tensors.clear(), h->layers.clear(), h->tensor_by_name.clear();
     h->t_input4 = add_tensor(h, "input", S, BOX, BOX, 3, 4);
     auto conv = [&](const std::string& scope, int in, int k, int stride, int cout, bool relu, int resid = -1,
@@ -685,13 +686,14 @@ int run_network(vnect_handle* h, bool timed)
 int run_pre(vnect_handle* h)
 {
     HIPCK(h, launch_squarify(h->d_fp, h->sq, h->st));
-    HIPCK(h, launch_pyramid(h->sq, h->d_stabs, h->tensors[h->t_input4].d, h->S, h->st));
+    HIPCK(h, launch_pyramid(h->sq, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
+                            h->sharded ? h->cfg.pyramid_rank : 0, h->st));
     return VNECT_OK;
 }
 
 int run_post(vnect_handle* h)
 {
-    HIPCK(h, launch_merge(h->tensors[h->t_out].d, h->d_mtabs, h->d_avg, h->S, h->st));
+    HIPCK(h, launch_merge(h->sharded ? h->gather : h->tensors[h->t_out].d, h->d_mtabs, h->d_avg, h->S, h->st));
     HIPCK(h, launch_argmax(h->d_avg, h->d_up, h->d_part, h->st));
     HIPCK(h, launch_joints(h->d_part, h->d_avg, h->d_fb, h->d_fp, h->cfg.numpy_promotion, h->d_out, h->st));
     return VNECT_OK;
@@ -728,6 +730,42 @@ int reset_filters_impl(vnect_handle* h)
     return VNECT_OK;
 }
 
+// ---- RCCL, opened lazily so single-GPU use never loads it -----------------------------------------------
+typedef struct { char internal[128]; } nccl_uid;
+void* g_rccl = nullptr;
+int (*p_ncclGetUniqueId)(nccl_uid*) = nullptr;
+int (*p_ncclCommInitRank)(void**, int, nccl_uid, int) = nullptr;
+int (*p_ncclAllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+int (*p_ncclCommDestroy)(void*) = nullptr;
+const char* (*p_ncclGetErrorString)(int) = nullptr;
+
+bool load_rccl()
+{
+    if (g_rccl) return true;
+    g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl) g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl) return false;
+    p_ncclGetUniqueId = (int (*)(nccl_uid*))dlsym(g_rccl, "ncclGetUniqueId");
+    p_ncclCommInitRank = (int (*)(void**, int, nccl_uid, int))dlsym(g_rccl, "ncclCommInitRank");
+    p_ncclAllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl, "ncclAllGather");
+    p_ncclCommDestroy = (int (*)(void*))dlsym(g_rccl, "ncclCommDestroy");
+    p_ncclGetErrorString = (const char* (*)(int))dlsym(g_rccl, "ncclGetErrorString");
+    if (p_ncclGetUniqueId && p_ncclCommInitRank && p_ncclAllGather && p_ncclCommDestroy) return true;
+    g_rccl = nullptr;
+    return false;
+}
+
+// rank r's (46,46,84) maps -> slot r of the (S,46,46,84) gather buffer on every rank (the one exchange of SURVEY 8e)
+int all_gather_maps(vnect_handle* h)
+{
+    if (!h->comm) return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init before inference");
+    const Tensor& t = h->tensors[h->t_out];
+    const int rc = p_ncclAllGather(t.d, h->gather, (size_t)HM * HM * MAPC, 7 /* ncclFloat32 */, h->comm, h->st);
+    if (rc != 0)
+        return fail(h, VNECT_E_COMM, std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"));
+    return VNECT_OK;
+}
+
 int run_frame_kernels(vnect_handle* h, bool timed)
 {
     const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
@@ -736,6 +774,7 @@ int run_frame_kernels(vnect_handle* h, bool timed)
     if (rc) return rc;
     rc = run_network(h, timed);
     if (rc) return rc;
+    if (h->sharded && (rc = all_gather_maps(h))) return rc;
     rc = run_post(h);
     if (rc) return rc;
     if (timed) HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
@@ -748,7 +787,7 @@ int build_graph(vnect_handle* h)
     if (h->graph) hipGraphDestroy(h->graph), h->graph = nullptr;
     if (h->pgexec) hipGraphExecDestroy(h->pgexec), h->pgexec = nullptr;
     if (h->pgraph) hipGraphDestroy(h->pgraph), h->pgraph = nullptr;
-    if (!h->cfg.use_graph) return VNECT_OK;
+    if (!h->cfg.use_graph || h->sharded) return VNECT_OK;  // sharded: the collective sits between net and post
     HIPCK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
     int rc = run_frame_kernels(h, false);
     hipError_t e = hipStreamEndCapture(h->st, &h->graph);
@@ -771,6 +810,8 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     if (slot < 0 || slot >= (int)h->slots.size() || h->slots[slot].H == 0)
         return fail(h, VNECT_E_ARG, "frame slot empty or out of range");
     if (h->seq_submit - h->seq_collect >= 2) return fail(h, VNECT_E_STATE, "two frames already in flight");
+    if (h->sharded && !h->comm)  // refuse before any filter / timestamp state changes
+        return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init before inference");
     const auto& si = h->slots[slot];
     FrameParams fp;
     int rc = squarify_params(h, si.H, si.W, &fp);
@@ -872,9 +913,14 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || !strstr(prop.gcnArchName, "gfx950"))
         return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: device is not gfx950 (MI355X); kernels are built for gfx950 only");
+    const bool sharded = cfg->pyramid_nranks > 1 || (cfg->pyramid_nranks == 1 && cfg->num_scales == 1);
+    if (sharded && (cfg->pyramid_nranks != cfg->num_scales || cfg->pyramid_rank < 0 || cfg->pyramid_rank >= cfg->pyramid_nranks))
+        return fail(nullptr, VNECT_E_ARG, "vnect_create: pyramid sharding needs pyramid_nranks == num_scales and 0 <= pyramid_rank < nranks");
     vnect_handle* h = new vnect_handle();
     h->cfg = *cfg;
     h->S = cfg->num_scales;
+    h->Snet = sharded ? 1 : cfg->num_scales;
+    h->sharded = sharded;
     if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
     if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
     *out = h;  // returned even on failure below so the caller can read the message, then destroy
@@ -894,6 +940,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_out, 1))) return rc;
     if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
+    if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
     for (int i = 0; i < RING; i++) {
         HIPCK(h, hipHostMalloc((void**)&h->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
         HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocDefault));
@@ -916,6 +963,7 @@ void vnect_destroy(vnect_handle* h)
     if (!h) return;
     hipSetDevice(h->cfg.device);
     if (h->st) hipStreamSynchronize(h->st);
+    if (h->comm && p_ncclCommDestroy) p_ncclCommDestroy(h->comm);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     if (h->graph) hipGraphDestroy(h->graph);
     if (h->pgexec) hipGraphExecDestroy(h->pgexec);
@@ -991,9 +1039,10 @@ int vnect_forward(vnect_handle* h, const float* batch, int num_images, float* ou
 {
     if (!h || !batch || !out) return VNECT_E_ARG;
     if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_forward before vnect_finalize");
-    if (num_images != h->S) return fail(h, VNECT_E_ARG, "vnect_forward: num_images must equal num_scales");
+    if (num_images != h->Snet)
+        return fail(h, VNECT_E_ARG, "vnect_forward: num_images must equal num_scales (1 on a pyramid-sharded handle)");
     HIPCK(h, hipSetDevice(h->cfg.device));
-    const long long npix = (long long)h->S * BOX * BOX;
+    const long long npix = (long long)h->Snet * BOX * BOX;
     HIPCK(h, hipMemcpyAsync(h->in3, batch, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->st));
     HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->st));
     int rc = run_network(h, false);
@@ -1020,7 +1069,7 @@ int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t 
     HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[0], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
     if ((rc = run_pre(h))) return rc;
     if (batch_out) {
-        const long long npix = (long long)h->S * BOX * BOX;
+        const long long npix = (long long)h->Snet * BOX * BOX;
         HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->st));
         HIPCK(h, hipMemcpyAsync(batch_out, h->in3, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->st));
     }
@@ -1041,8 +1090,8 @@ int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d
     HIPCK(h, hipSetDevice(h->cfg.device));
     int rc = check_time(h, t2d, t3d);
     if (rc) return rc;
-    const Tensor& t = h->tensors[h->t_out];
-    HIPCK(h, hipMemcpyAsync(t.d, maps, t.floats() * sizeof(float), hipMemcpyHostToDevice, h->st));
+    float* dst = h->sharded ? h->gather : h->tensors[h->t_out].d;
+    HIPCK(h, hipMemcpyAsync(dst, maps, (size_t)h->S * HM * HM * MAPC * sizeof(float), hipMemcpyHostToDevice, h->st));
     FrameParams fp;
     memset(&fp, 0, sizeof fp);
     fp.t2d = t2d, fp.t3d = t3d, fp.scaler = scaler, fp.offx = offset_x, fp.offy = offset_y;
@@ -1167,23 +1216,6 @@ int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out)
     return VNECT_OK;
 }
 
-// ---- RCCL pyramid sharding; librccl is opened lazily so single-GPU use never loads it ----
-typedef struct { char internal[128]; } nccl_uid;
-static void* g_rccl = nullptr;
-static int (*p_ncclGetUniqueId)(nccl_uid*) = nullptr;
-static int (*p_ncclCommInitRank)(void**, int, nccl_uid, int) = nullptr;
-
-static bool load_rccl()
-{
-    if (g_rccl) return true;
-    g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl) g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl) return false;
-    p_ncclGetUniqueId = (int (*)(nccl_uid*))dlsym(g_rccl, "ncclGetUniqueId");
-    p_ncclCommInitRank = (int (*)(void**, int, nccl_uid, int))dlsym(g_rccl, "ncclCommInitRank");
-    return p_ncclGetUniqueId && p_ncclCommInitRank;
-}
-
 int vnect_comm_unique_id(void* id128)
 {
     if (!id128) return VNECT_E_ARG;
@@ -1197,7 +1229,20 @@ int vnect_comm_unique_id(void* id128)
 int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128)
 {
     if (!h || !id128) return VNECT_E_ARG;
-    return fail(h, VNECT_E_COMM, "pyramid sharding over RCCL is not built in this round");
+    if (!h->sharded) return fail(h, VNECT_E_STATE, "vnect_comm_init: handle was not created with pyramid_nranks");
+    if (h->comm) return fail(h, VNECT_E_STATE, "vnect_comm_init: communicator already initialised");
+    if (nranks != h->cfg.pyramid_nranks || rank != h->cfg.pyramid_rank)
+        return fail(h, VNECT_E_ARG, "vnect_comm_init: rank / nranks differ from the handle's pyramid configuration");
+    if (!load_rccl()) return fail(h, VNECT_E_COMM, "librccl.so not available");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    nccl_uid u;
+    memcpy(&u, id128, sizeof u);
+    const int rc = p_ncclCommInitRank(&h->comm, nranks, u, rank);
+    if (rc != 0) {
+        h->comm = nullptr;
+        return fail(h, VNECT_E_COMM, std::string("ncclCommInitRank: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"));
+    }
+    return VNECT_OK;
 }
 
 }  // extern "C"
