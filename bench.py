@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 SCALES = [1.0, 0.8, 0.6]
 FLOPS_PER_FRAME = 71.49e9      # 23.83 GFLOP per image x 3 scales (live graph, 2*MAC)
 PEAK_FP32_MFMA = 157.3         # TFLOP/s, MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
+BF16_BYTES_PER_FRAME = 29.2e6 + 2 * 3 * 58.7e6   # see the roofline comment in main()
+PEAK_BF16_MFMA = 2500.0        # TFLOP/s dense bf16 (same table; the 2:1-sparsity figure is not used)
 
 
 def cpu_baseline(weights, budget_s):
@@ -50,6 +52,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2] (bf16 MFMA conv path)")
     ap.add_argument("--pyramid", action="store_true",
                     help="BASELINE.json configs[3]: ONE stream, one scale per GPU (needs --gpus 3), RCCL all-gather of the "
                          "maps; default for N>1 is N independent streams (configs[4])")
@@ -74,12 +78,13 @@ def main():
     rank, local_rank = grp.rank, grp.local_rank
 
     weights = synthetic_weights()
+    prec = _native.BF16 if args.precision == "bf16" else _native.FP32
     if args.pyramid:
         if args.gpus != len(SCALES):
             sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
-        h = _native.Handle(SCALES, device=local_rank, num_frame_slots=8, pyramid=(rank, world))
+        h = _native.Handle(SCALES, device=local_rank, num_frame_slots=8, pyramid=(rank, world), precision=prec)
     else:
-        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8)
+        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec)
     h.set_weights(weights)
     h.finalize()
     if args.pyramid:  # rank 0 makes the ncclUniqueId, torch.distributed carries it to the others
@@ -146,28 +151,40 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get("hbm_bytes_per_frame")
+        peak = PEAK_FP32_MFMA if args.precision == "fp32" else PEAK_BF16_MFMA
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": "frames/sec, 368x368 3-scale VNect inference",
             "value": round(aggregate_rate(1 if args.pyramid else args.gpus, args.steps, elapsed), 2),
             "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if args.pyramid else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "368x368x3 uint8 BGR frame -> 21 joints; scales [1.0,0.8,0.6]; fp32; batch 1 "
-                                   "(BASELINE.json configs[1]); N>1 = N independent streams, one per GPU",
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "368x368x3 uint8 BGR frame -> 21 joints; scales [1.0,0.8,0.6]; %s; batch 1 "
+                                   "(BASELINE.json configs[%d]); N>1 = N independent streams, one per GPU"
+                                   % (("fp32", 1) if args.precision == "fp32" else ("bf16 operands, fp32 accumulate", 2)),
                        "weights": "seeded synthetic (reference ships none)", "frames_resident_in_hbm": True,
                        "hip_graph": not args.no_graph and not args.pyramid, "sync_per_frame": True,
                        "parallelism": "pyramid: 1 scale per GPU + RCCL all-gather" if args.pyramid else "stream replicas"},
             "pipelined_frames_per_s_per_gpu": round(pipelined, 2),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-                         "kernel": "vnect::conv_f32_glds_kernel<64,64,5> (%d launches per frame)" % tim["conv_launches"],
-                         "launches_per_frame": tim["conv_launches"],
-                         "avg_launch_us": round(conv_ms * 1e3 / tim["conv_launches"], 3),
-                         "kernel_ms_per_frame": round(conv_ms, 4), "flops_per_frame": FLOPS_PER_FRAME,
-                         "conv_stack_span_ms": round(tim["net_ms"] / nprof, 4),
-                         "hip_event_frame_ms": round(tim["total_ms"] / nprof, 4),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, profiles/ (per frame)"},
+            "roofline": dict(
+                         # fp32: the conv stack is MFMA-bound.  bf16: 16x the MFMA rate makes the
+                         # same stack memory/latency-bound -- priced against HBM with its algorithmic bytes (bf16 weights
+                         # 29.2 MB + every layer output written once and read once: 2 x 3 x 58.7 MB); the MFMA view is kept.
+                         **({"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+                             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic} if args.precision == "fp32" else
+                            {"bound": "hbm", "achieved": round(BF16_BYTES_PER_FRAME / (conv_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(BF16_BYTES_PER_FRAME / (conv_ms * 1e-3) / 8e12, 4), "traffic": None,
+                             "algorithmic_bytes_per_frame": BF16_BYTES_PER_FRAME,
+                             "mfma_view": {"achieved_tflops": round(achieved, 2), "peak": PEAK_BF16_MFMA,
+                                           "frac": round(achieved / PEAK_BF16_MFMA, 4)}}),
+                         kernel="vnect::conv_glds_kernel<64,64,5,%s> (%d launches per frame)"
+                                % ("false" if args.precision == "fp32" else "true", tim["conv_launches"]),
+                         launches_per_frame=tim["conv_launches"],
+                         avg_launch_us=round(conv_ms * 1e3 / tim["conv_launches"], 3),
+                         kernel_ms_per_frame=round(conv_ms, 4), flops_per_frame=FLOPS_PER_FRAME,
+                         conv_stack_span_ms=round(tim["net_ms"] / nprof, 4),
+                         hip_event_frame_ms=round(tim["total_ms"] / nprof, 4),
+                         traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, profiles/ (per frame)"),
         }
     h.close()
     if rank == 0:

@@ -12,10 +12,14 @@
 // chunks go global -> LDS by LDS-DMA into a ring of stages (details at the kernel).
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace vnect {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDT = 36;  // LDS row pitch in floats (32 + 4)
 
@@ -36,9 +40,16 @@ __device__ __forceinline__ void wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
+// BF = false: fp32 operands, v_mfma_f32_32x32x2_f32 (exact f32), a 128-B LDS row holds 32 K-elements.
+// BF = true : bf16 operands (activations and weights stored as bf16, fp32 accumulate), v_mfma_f32_32x32x16_bf16,
+//             a 128-B row holds 64 K-elements, so the same ring / swizzle / fragment addressing moves twice the K
+//             per byte: lane half h of MFMA step q reads the 16-B unit 2q+h = k 16q+8h..+7 of its row.
+template <int BM, int BN, int NS, bool BF>
+__global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
 {
+    using T = typename std::conditional<BF, __bf16, float>::type;
+    constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
+    constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;  // floats per ring stage (128-B rows, no padding)
     constexpr int NLD = AR + BR;           // LDS-DMA instructions per thread per chunk
@@ -88,8 +99,9 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
         if (m < a.M) {
             int ox = m % a.Wo, t = m / a.Wo;
             int oy = t % a.Ho, s = t / a.Ho;
-            a_iy[i] = oy * a.stride;
-            a_ix[i] = ox * a.stride + (pix ? unit : 0);
+            // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
+            a_iy[i] = oy * a.stride + (pix && BF ? unit >> 2 : 0);
+            a_ix[i] = ox * a.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
             a_pix[i] = s * a.H * a.W;
         } else {
             a_iy[i] = -(1 << 20);
@@ -97,10 +109,10 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
             a_pix[i] = 0;
         }
     }
-    const float* __restrict__ inp = a.in;
-    const float* __restrict__ zero = a.zeros;
-    const float* __restrict__ wp =
-        a.w + (long long)phase * a.w_phase_stride + (long long)(n0 + srow) * a.K + unit * 4 + (long long)c0 * 32;
+    const T* __restrict__ inp = (const T*)a.in;
+    const T* __restrict__ zero = (const T*)a.zeros;
+    const T* __restrict__ wp =
+        (const T*)a.w + (long long)phase * a.w_phase_stride + (long long)(n0 + srow) * a.K + unit * EPU + (long long)c0 * EPR;
     const int* dyp = a.dy + phase * a.ntaps;
     const int* dxp = a.dx + phase * a.ntaps;
 
@@ -113,19 +125,19 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
         for (int i = 0; i < AR; i++) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             a_ok[i] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            a_off[i] = (a_pix[i] + iy * a.W + ix) * a.Cs + (pix ? 0 : unit * 4);
+            a_off[i] = (a_pix[i] + iy * a.W + ix) * a.Cs + (pix ? 0 : unit * EPU);
         }
     };
     auto issue = [&](int stage) {
         float* sb = smem + stage * STAGE + wave * (8 * 32);  // wave-uniform; the hardware adds lane * 16 B
 #pragma unroll
         for (int i = 0; i < AR; i++) {
-            const float* src = a_ok[i] ? inp + a_off[i] + cc * 32 : zero;
+            const T* src = a_ok[i] ? inp + a_off[i] + cc * EPR : zero;
             GLDS16(src, sb + i * (32 * 32));
         }
 #pragma unroll
         for (int i = 0; i < BR; i++) GLDS16(wp + (long long)i * 32 * a.K, sb + BM * 32 + i * (32 * 32));
-        wp += 32;
+        wp += EPR;
         if (++cc == a.cpt) {
             cc = 0;
             if (++tap < a.ntaps) set_tap(tap);
@@ -162,7 +174,10 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
                     const int m = m0 + wm * WM + i * 32 + erow + 8 * k;
                     const int n = n0 + wn * WN + j * 32 + ecol;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (m < a.M && n < nlim) v = *(const f32x4*)(resid + (long long)m * a.ldr + n);  // shortcut layers: os == 1
+                    if (m < a.M && n < nlim) {  // shortcut layers: os == 1
+                        if constexpr (BF) v = __builtin_convertvector(*(const bf16x4*)((const __bf16*)resid + (long long)m * a.ldr + n), f32x4);
+                        else v = *(const f32x4*)(resid + (long long)m * a.ldr + n);
+                    }
                     rs[i][j][k] = v;
                 }
     }
@@ -188,13 +203,22 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
         for (int j = 0; j < TN; j++) bf[j] = *(const f32x4*)(Bb + j * (32 * 32));
     };
     auto mma = [&](const f32x4(&af)[TM], const f32x4(&bf)[TN]) {
-#pragma unroll
-        for (int e = 0; e < 4; e++)
+        if constexpr (BF) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                       __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
     };
 
     if (producer) {
@@ -244,7 +268,7 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
         // after the last chunk the barrier and the reads still run (the reads fetch stale ring data that is never
         // used): no branch sits between the MFMAs
         __builtin_amdgcn_s_barrier();  // chunk t+1 visible; every consumer is past chunk t-1
-        if constexpr (TM == 1 && TN == 1) {
+        if constexpr (TM == 1 && TN == 1 && !BF) {
             const float* Ab = smem + nstage * STAGE + (wm * WM) * 32;
             const float* Bb = smem + nstage * STAGE + (BM + wn * WN) * 32;
 #pragma unroll
@@ -284,8 +308,10 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
     // Two layers that read the same input run as one GEMM (columns [0, split_n) -> out, the rest -> out2): the whole
     // 64-wide tile lies on one side because split_n is a multiple of the tile width.
     const bool second = fused && a.out2 != nullptr && n0 >= a.split_n;
-    float* __restrict__ outp = !fused ? a.ws + (long long)ks * npix * a.Npad : (second ? a.out2 - a.split_n : a.out);
+    float* __restrict__ outp = !fused ? a.ws + (long long)ks * npix * a.Npad : (second ? a.out2 : a.out);
+    const int ncol0 = second ? a.split_n : 0;  // first column of the tensor written by this tile
     const int ldo = !fused ? a.Npad : (second ? a.ldc2 : a.ldc);
+    const bool of32 = !BF || !fused || a.out_f32;  // split-K slabs and the final maps stay fp32
     float* scr = smem + wave * (32 * LDT);
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -323,13 +349,25 @@ __global__ __launch_bounds__(512) void conv_f32_glds_kernel(const ConvArgs a)
                         if (n + e < a.relu_cols) o[e] = o[e] > 0.f ? o[e] : 0.f;
                 }
                 if (!(m < a.M && n < nlim)) continue;
-                float* dst = outp + op * ldo + n;
-                if (vec) {
-                    *(f32x4*)dst = o;
-                } else {
+                if (of32) {
+                    float* dst = outp + op * ldo + (n - ncol0);
+                    if (vec) {
+                        *(f32x4*)dst = o;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (n + e < nlim) dst[e] = o[e];
+                        for (int e = 0; e < 4; e++)
+                            if (n + e < nlim) dst[e] = o[e];
+                    }
+                } else {
+                    __bf16* dst = (__bf16*)outp + op * ldo + (n - ncol0);
+                    const bf16x4 ob = __builtin_convertvector(o, bf16x4);  // round to nearest even (v_cvt_pk_bf16_f32)
+                    if (vec) {
+                        *(bf16x4*)dst = ob;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (n + e < nlim) dst[e] = ob[e];
+                    }
                 }
             }
         }
@@ -363,9 +401,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
             if (c >= a.Nvalid) continue;
             float v = s[e] + a.bias[c];
             if (a.scale) v = v * a.scale[c] + a.shift[c];
-            if (a.resid) v = v + a.resid[pix * a.ldr + c];
+            if (a.resid) v = v + (a.bf16 ? (float)((const __bf16*)a.resid)[pix * a.ldr + c] : a.resid[pix * a.ldr + c]);
             if (c < a.relu_cols) v = v > 0.f ? v : 0.f;
-            a.out[pix * a.ldc + c] = v;
+            if (a.bf16 && !a.out_f32) ((__bf16*)a.out)[pix * a.ldc + c] = (__bf16)v;
+            else a.out[pix * a.ldc + c] = v;
         }
     }
 }
@@ -376,7 +415,8 @@ static hipError_t launch_g(ConvArgs a, hipStream_t st)
     a.tiles_m = (a.M + BM - 1) / BM, a.tiles_n = a.Npad / BN;
     dim3 grid(a.tiles_m * a.tiles_n * a.nphase * a.ksplit);
     size_t lds = (size_t)NS * (BM + BN) * 32 * sizeof(float);
-    hipLaunchKernelGGL((conv_f32_glds_kernel<BM, BN, NS>), grid, dim3(512), lds, st, a);
+    if (a.bf16) hipLaunchKernelGGL((conv_glds_kernel<BM, BN, NS, true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_glds_kernel<BM, BN, NS, false>), grid, dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -386,7 +426,10 @@ hipError_t conv_setup()
 {
     hipError_t e;
 #define SETG(BM, BN, NS)                                                                                       \
-    e = hipFuncSetAttribute((const void*)conv_f32_glds_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    e = hipFuncSetAttribute((const void*)conv_glds_kernel<BM, BN, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            NS * (BM + BN) * 32 * (int)sizeof(float));                                          \
+    if (e != hipSuccess) return e;                                                                              \
+    e = hipFuncSetAttribute((const void*)conv_glds_kernel<BM, BN, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             NS * (BM + BN) * 32 * (int)sizeof(float));                                          \
     if (e != hipSuccess) return e;
     SETG(64, 64, 5) SETG(128, 64, 3) SETG(64, 128, 3)
@@ -396,8 +439,9 @@ hipError_t conv_setup()
 
 hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
 {
-    if (a.Npad % BN != 0 || a.K % 32 != 0 || a.K != a.ntaps * a.cpt * 32 || a.nphase * a.ntaps > MAX_TAPS ||
-        a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || !a.zeros)
+    const int epr = a.bf16 ? 64 : 32;
+    if (a.Npad % BN != 0 || a.K != a.ntaps * a.cpt * epr || a.nphase * a.ntaps > MAX_TAPS ||
+        a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || !a.zeros || (a.bf16 && a.out2 && a.split_n % 64))
         return hipErrorInvalidValue;
     if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);
     if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
@@ -414,37 +458,42 @@ hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-// ---- layout helpers -------------------------------------------------------------------------
-__global__ void pad3to4_kernel(const float* __restrict__ in3, float* __restrict__ out4, long long npix)
+// ---- layout helpers (T = float or __bf16 activations) ------------------------------------------------
+template <typename T>
+__global__ void pad3to4_kernel(const float* __restrict__ in3, T* __restrict__ out4, long long npix)
 {
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    f32x4 v = {in3[p * 3], in3[p * 3 + 1], in3[p * 3 + 2], 0.f};
-    *(f32x4*)(out4 + p * 4) = v;
+    out4[p * 4 + 0] = (T)in3[p * 3], out4[p * 4 + 1] = (T)in3[p * 3 + 1], out4[p * 4 + 2] = (T)in3[p * 3 + 2], out4[p * 4 + 3] = (T)0.f;
 }
-__global__ void strip4to3_kernel(const float* __restrict__ in4, float* __restrict__ out3, long long npix)
+template <typename T>
+__global__ void strip4to3_kernel(const T* __restrict__ in4, float* __restrict__ out3, long long npix)
 {
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    f32x4 v = *(const f32x4*)(in4 + p * 4);
-    out3[p * 3] = v[0], out3[p * 3 + 1] = v[1], out3[p * 3 + 2] = v[2];
+    out3[p * 3] = (float)in4[p * 4], out3[p * 3 + 1] = (float)in4[p * 4 + 1], out3[p * 3 + 2] = (float)in4[p * 4 + 2];
 }
-hipError_t launch_pad3to4(const float* in3, float* out4, long long npix, hipStream_t st)
+hipError_t launch_pad3to4(const float* in3, void* out4, long long npix, int bf16, hipStream_t st)
 {
-    hipLaunchKernelGGL(pad3to4_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, in3, out4, npix);
+    dim3 g((unsigned)((npix + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(pad3to4_kernel<__bf16>, g, dim3(256), 0, st, in3, (__bf16*)out4, npix);
+    else hipLaunchKernelGGL(pad3to4_kernel<float>, g, dim3(256), 0, st, in3, (float*)out4, npix);
     return hipGetLastError();
 }
-hipError_t launch_strip4to3(const float* in4, float* out3, long long npix, hipStream_t st)
+hipError_t launch_strip4to3(const void* in4, float* out3, long long npix, int bf16, hipStream_t st)
 {
-    hipLaunchKernelGGL(strip4to3_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, in4, out3, npix);
+    dim3 g((unsigned)((npix + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(strip4to3_kernel<__bf16>, g, dim3(256), 0, st, (const __bf16*)in4, out3, npix);
+    else hipLaunchKernelGGL(strip4to3_kernel<float>, g, dim3(256), 0, st, (const float*)in4, out3, npix);
     return hipGetLastError();
 }
 
 // MaxPool 3x3 stride 2, TF SAME (pad 0 before / 1 after for 184 -> 92): padding never wins.
-// One thread = 4 channels of one output pixel (float4 loads, coalesced over channels).
-__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int S, int H, int W, int C,
-                               int Ho, int Wo)
+// One thread = 4 channels of one output pixel (coalesced over channels).
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int S, int H, int W, int C, int Ho, int Wo)
 {
+    typedef T tx4 __attribute__((ext_vector_type(4)));
     const int c4 = C >> 2;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)S * Ho * Wo * c4;
@@ -462,42 +511,46 @@ __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__
         for (int kx = 0; kx < 3; kx++) {
             int ix = ox * 2 + kx;
             if (ix >= W) continue;
-            f32x4 v = *(const f32x4*)(in + (((long long)s * H + iy) * W + ix) * C + c);
+            f32x4 v = __builtin_convertvector(*(const tx4*)(in + (((long long)s * H + iy) * W + ix) * C + c), f32x4);
 #pragma unroll
             for (int e = 0; e < 4; e++) m[e] = v[e] > m[e] ? v[e] : m[e];
         }
     }
-    *(f32x4*)(out + p * C + c) = m;
+    *(tx4*)(out + p * C + c) = __builtin_convertvector(m, tx4);  // exact: the maximum is one of the inputs
 }
-hipError_t launch_maxpool(const float* in, float* out, int S, int H, int W, int C, int Ho, int Wo, hipStream_t st)
+hipError_t launch_maxpool(const void* in, void* out, int S, int H, int W, int C, int Ho, int Wo, int bf16, hipStream_t st)
 {
     long long total = (long long)S * Ho * Wo * (C >> 2);
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, S, H, W, C, Ho,
-                       Wo);
+    dim3 g((unsigned)((total + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(maxpool_kernel<__bf16>, g, dim3(256), 0, st, (const __bf16*)in, (__bf16*)out, S, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool_kernel<float>, g, dim3(256), 0, st, (const float*)in, (float*)out, S, H, W, C, Ho, Wo);
     return hipGetLastError();
 }
 
 // Bone-length features (vnect_model.py:198-209): feat[p][191+j] = sqrt((dx^2 + dy^2) + dz^2) from the
 // delta channels feat[p][128+j], [149+j], [170+j]; channels 212..ld-1 are zero padding for the next conv.
-__global__ void bone_kernel(float* feat, long long npix, int ld)
+template <typename T>
+__global__ void bone_kernel(T* feat, long long npix, int ld)
 {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = ld - 191;
     if (idx >= npix * per) return;
     long long p = idx / per;
     int j = (int)(idx - p * per);
-    float* f = feat + p * ld;
+    T* f = feat + p * ld;
     float v = 0.f;
     if (j < 21) {
-        float x = f[128 + j], y = f[149 + j], z = f[170 + j];
+        float x = (float)f[128 + j], y = (float)f[149 + j], z = (float)f[170 + j];
         v = sqrtf((x * x + y * y) + z * z);
     }
-    f[191 + j] = v;
+    f[191 + j] = (T)v;
 }
-hipError_t launch_bone(float* feat, long long npix, int ld, hipStream_t st)
+hipError_t launch_bone(void* feat, long long npix, int ld, int bf16, hipStream_t st)
 {
     long long total = npix * (ld - 191);
-    hipLaunchKernelGGL(bone_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feat, npix, ld);
+    dim3 g((unsigned)((total + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(bone_kernel<__bf16>, g, dim3(256), 0, st, (__bf16*)feat, npix, ld);
+    else hipLaunchKernelGGL(bone_kernel<float>, g, dim3(256), 0, st, (float*)feat, npix, ld);
     return hipGetLastError();
 }
 

@@ -39,7 +39,9 @@ struct ConvArgs {
     int nphase;           // 1, or 4 for the transposed conv (py = phase>>1, px = phase&1)
     int ksplit;
     int relu_cols;        // ReLU on columns < relu_cols
-    int pixmode;          // conv1: a 32-float chunk is 8 consecutive NHWC4 pixels of one input row
+    int pixmode;          // conv1: a chunk row is 8 consecutive NHWC4 pixels of one input row (bf16: of two rows)
+    int bf16;             // operands and activations are bf16 (accumulators, bias, slabs stay fp32)
+    int out_f32;          // bf16 path: this layer writes fp32 (the final maps feed the f64 post-processing)
     int tiles_m, tiles_n; // filled by the launcher
     long long w_phase_stride;
     int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
@@ -54,16 +56,17 @@ struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])
     float* out;
     long long npix;
     int Npad, Nvalid, ldc, ldr, ksplit, relu_cols;
+    int bf16, out_f32;
 };
 
 hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
 hipError_t conv_setup();  // one-time function attributes (dynamic LDS size)
 
-hipError_t launch_pad3to4(const float* in3, float* out4, long long npix, hipStream_t st);
-hipError_t launch_strip4to3(const float* in4, float* out3, long long npix, hipStream_t st);
-hipError_t launch_maxpool(const float* in, float* out, int S, int H, int W, int C, int Ho, int Wo, hipStream_t st);
-hipError_t launch_bone(float* feat, long long npix, int ld, hipStream_t st);
+hipError_t launch_pad3to4(const float* in3, void* out4, long long npix, int bf16, hipStream_t st);
+hipError_t launch_strip4to3(const void* in4, float* out3, long long npix, int bf16, hipStream_t st);
+hipError_t launch_maxpool(const void* in, void* out, int S, int H, int W, int C, int Ho, int Wo, int bf16, hipStream_t st);
+hipError_t launch_bone(void* feat, long long npix, int ld, int bf16, hipStream_t st);
 
 // ---- pre-processing -------------------------------------------------------------------
 struct ResizeTab {  // 8-bit bilinear tables for one destination axis pair (OpenCV fixed point, 11 bits)
@@ -93,7 +96,7 @@ struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.
 };
 
 hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st);
-hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, int scale_base, hipStream_t st);
+hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
 // ---- post-processing ------------------------------------------------------------------
 struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale

@@ -55,9 +55,11 @@ __global__ void squarify_kernel(const FrameParams* __restrict__ fp, uint8_t* __r
 }
 
 // utils.img_scale_padding per scale + `/255 - 0.4` (estimator.py:76-80) -> (S,368,368,4) f32, 4th = 0
+template <typename T>
 __global__ void pyramid_kernel(const uint8_t* __restrict__ sq, const ScaleTabs* __restrict__ tabs,
-                               float* __restrict__ batch4, int scale_base)
+                               T* __restrict__ batch4, int scale_base)
 {
+    typedef T tx4 __attribute__((ext_vector_type(4)));
     // image blockIdx.z of the batch is scale (scale_base + blockIdx.z): a pyramid-sharded rank builds one scale only
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, s = blockIdx.z + scale_base;
     if (x >= BOX) return;
@@ -78,7 +80,7 @@ __global__ void pyramid_kernel(const uint8_t* __restrict__ sq, const ScaleTabs* 
         }
     }
     f32x4 o = {tabs->lut[v[0]], tabs->lut[v[1]], tabs->lut[v[2]], 0.f};
-    *(f32x4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4) = o;
+    *(tx4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4) = __builtin_convertvector(o, tx4);
 }
 
 hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st)
@@ -86,9 +88,11 @@ hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st)
     hipLaunchKernelGGL(squarify_kernel, dim3((BOX + 127) / 128, BOX), dim3(128), 0, st, fp, sq);
     return hipGetLastError();
 }
-hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, float* batch4, int S, int scale_base, hipStream_t st)
+hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st)
 {
-    hipLaunchKernelGGL(pyramid_kernel, dim3((BOX + 127) / 128, BOX, S), dim3(128), 0, st, sq, tabs, batch4, scale_base);
+    dim3 g((BOX + 127) / 128, BOX, S);
+    if (bf16) hipLaunchKernelGGL(pyramid_kernel<__bf16>, g, dim3(128), 0, st, sq, tabs, (__bf16*)batch4, scale_base);
+    else hipLaunchKernelGGL(pyramid_kernel<float>, g, dim3(128), 0, st, sq, tabs, (float*)batch4, scale_base);
     return hipGetLastError();
 }
 

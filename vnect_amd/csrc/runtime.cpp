@@ -27,9 +27,11 @@ struct HostArray {
 
 struct Tensor {
     std::string name;
-    int S = 0, H = 0, W = 0, C = 0, Cs = 0;  // C valid channels, Cs floats per pixel
-    float* d = nullptr;
-    size_t floats() const { return (size_t)S * H * W * Cs; }
+    int S = 0, H = 0, W = 0, C = 0, Cs = 0;  // C valid channels, Cs elements per pixel
+    int esz = 4;                             // bytes per element: 4 (fp32) or 2 (bf16)
+    float* d = nullptr;                      // device buffer (bf16 data when esz == 2)
+    size_t elems() const { return (size_t)S * H * W * Cs; }
+    size_t bytes() const { return elems() * esz; }
 };
 
 enum OpKind { OP_CONV, OP_POOL, OP_BONE };
@@ -57,6 +59,7 @@ struct vnect_handle {
     int Snet = 0;   // images this handle pushes through the conv stack: S, or 1 when pyramid-sharded
     std::string err;
     bool finalized = false;
+    bool bf16 = false;  // VNECT_BF16: bf16 activations + weights, fp32 accumulate; final maps and post-processing stay fp32/f64
     hipStream_t st = nullptr;
     std::map<std::string, HostArray> weights;
     std::vector<Tensor> tensors;
@@ -143,6 +146,32 @@ int upload(vnect_handle* h, T** dst, const std::vector<T>& v)
     if (rc) return rc;
     HIPCK(h, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return VNECT_OK;
+}
+
+// fp32 -> bf16, round to nearest even (weights are finite)
+uint16_t to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+float from_bf16(uint16_t b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// packed weights: fp32 as is, or converted to bf16 (the device pointer is typed float* either way)
+int upload_weights(vnect_handle* h, float** dst, const std::vector<float>& v)
+{
+    if (!h->bf16) return upload(h, dst, v);
+    std::vector<uint16_t> b(v.size());
+    for (size_t i = 0; i < v.size(); i++) b[i] = to_bf16(v[i]);
+    uint16_t* p = nullptr;
+    int rc = upload(h, &p, b);
+    *dst = (float*)p;
+    return rc;
 }
 
 // ---- OpenCV INTER_LINEAR table builders (resize.cpp semantics) ----------------------
@@ -292,10 +321,11 @@ int squarify_params(vnect_handle* h, int H, int W, FrameParams* fp)
 }
 
 // ---- network construction --------------------------------------------------------------------------
-int add_tensor(vnect_handle* h, const std::string& name, int S, int H, int W, int C, int Cs)
+int add_tensor(vnect_handle* h, const std::string& name, int S, int H, int W, int C, int Cs, bool force_f32 = false)
 {
     Tensor t;
     t.name = name, t.S = S, t.H = H, t.W = W, t.C = C, t.Cs = Cs;
+    t.esz = (h->bf16 && !force_f32) ? 2 : 4;
     h->tensors.push_back(t);
     h->tensor_by_name[name] = (int)h->tensors.size() - 1;
     return (int)h->tensors.size() - 1;
@@ -333,9 +363,10 @@ void choose_tile(Layer& L, long long npix)
 {
     (void)npix;
     const int nch = L.a.ntaps * L.a.cpt;
+    const int kel = L.a.K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
     int BM = 64, BN = 64, ks = 1;
     const long long tiles = (long long)((L.a.M + 63) / 64) * (round_up(L.Nreal, 64) / 64) * L.a.nphase;
-    if ((tiles <= 128 && nch >= 24) || (tiles <= 200 && nch >= 128)) ks = 5;
+    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) ks = std::min(5, nch);
     const char* force = getenv("VNECT_FORCE_TILE");
     if (force) {
         int fBM = 0, fBN = 0, fks = 0;
@@ -367,8 +398,10 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     else same_pad(tin.H, sp.k, sp.stride, &ho, &pt), same_pad(tin.W, sp.k, sp.stride, &wo, &pl);
     Layer L;
     L.op = OP_CONV, L.name = sp.scope, L.in = sp.in, L.resid = sp.resid;
-    L.out = add_tensor(h, sp.out_name, tin.S, ho, wo, sp.cout, sp.cout);
+    const bool final_maps = sp.scope == "res5c_branch2c";  // feeds the f64 post-processing: stays fp32
+    L.out = add_tensor(h, sp.out_name, tin.S, ho, wo, sp.cout, sp.cout, final_maps);
     ConvArgs& a = L.a;
+    a.out_f32 = final_maps;
     a.S = tin.S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
     a.Ho = ho, a.Wo = wo, a.M = tin.S * ho * wo;
     a.stride = sp.stride;
@@ -377,22 +410,26 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     a.relu_cols = sp.relu ? sp.cout : 0;
     a.Nvalid = sp.cout;
     L.Nreal = sp.cout;
+    const int EPR = h->bf16 ? 64 : 32;  // K-elements per chunk
+    a.bf16 = h->bf16;
     int cp;  // channels per tap in the packed K
     if (conv1) {
-        // K = 7 rows x (8 pixels x 4 channels): pixel 7 and channel 3 carry zero weights
-        a.pixmode = 1, a.ntaps = 7, a.cpt = 1, cp = 32;
-        for (int ky = 0; ky < 7; ky++) a.dy[ky] = (int)(ky - pt), a.dx[ky] = (int)(-pl);
+        // fp32: K = 7 rows x (8 pixels x 4 channels); bf16: K = 4 row pairs x (2 rows x 8 pixels x 4 channels).
+        // Pixel 7, channel 3 (and row 7 in bf16) carry zero weights.
+        a.pixmode = 1, a.cpt = 1, cp = 32;
+        a.ntaps = h->bf16 ? 4 : 7;
+        for (int t = 0; t < a.ntaps; t++) a.dy[t] = (int)((h->bf16 ? 2 * t : t) - pt), a.dx[t] = (int)(-pl);
     } else {
-        cp = round_up(tin.Cs, 32);
+        cp = round_up(tin.Cs, EPR);
         if (cp != tin.Cs) {
-            h->err = "internal: input channel stride not a multiple of 32 at " + sp.scope;
+            h->err = "internal: input channel stride not a multiple of the chunk at " + sp.scope;
             return -1;
         }
-        a.pixmode = 0, a.ntaps = sp.k * sp.k, a.cpt = cp / 32;
+        a.pixmode = 0, a.ntaps = sp.k * sp.k, a.cpt = cp / EPR;
         for (int ky = 0; ky < sp.k; ky++)
             for (int kx = 0; kx < sp.k; kx++) a.dy[ky * sp.k + kx] = (int)(ky - pt), a.dx[ky * sp.k + kx] = (int)(kx - pl);
     }
-    a.K = a.ntaps * a.cpt * 32;
+    a.K = a.ntaps * a.cpt * EPR;
     L.Kreal = sp.k * sp.k * cin;
     L.flops = 2.0 * a.M * (double)L.Kreal * sp.cout;
     choose_tile(L, (long long)a.M);
@@ -402,11 +439,12 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
         for (int kx = 0; kx < sp.k; kx++)
             for (int ci = 0; ci < cin; ci++) {
                 const float* src = &W->d[(((size_t)ky * sp.k + kx) * cin + ci) * sp.cout];
-                const size_t kidx = conv1 ? (size_t)ky * 32 + kx * 4 + ci : (size_t)(ky * sp.k + kx) * cp + ci;
+                const size_t kidx = conv1 ? (h->bf16 ? (size_t)(ky >> 1) * 64 + (ky & 1) * 32 + kx * 4 + ci : (size_t)ky * 32 + kx * 4 + ci)
+                                          : (size_t)(ky * sp.k + kx) * cp + ci;
                 for (int n = 0; n < sp.cout; n++) wp[(size_t)n * a.K + kidx] = src[n];
             }
     for (int n = 0; n < sp.cout; n++) bp[n] = B->d[n];
-    if (upload(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
+    if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
     h->layers.push_back(L);
     return L.out;
 }
@@ -424,7 +462,8 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     const HostArray* Wb = Ba ? get_w(h, sb + "/weights", {1, 1, cin, cout_b}) : nullptr;
     const HostArray* Bb = Wb ? get_w(h, sb + "/biases", {cout_b}) : nullptr;
     if (!Bb) return -1;
-    if (cout_a % 64 || tin.Cs % 32) {
+    const int EPR = h->bf16 ? 64 : 32;
+    if (cout_a % 64 || tin.Cs % EPR) {
         h->err = "internal: paired conv needs 64-aligned split";
         return -1;
     }
@@ -439,7 +478,8 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     a.OH = ho, a.OW = wo, a.os = 1, a.nphase = 1;
     a.ldc = cout_a, a.ldc2 = cout_b, a.split_n = cout_a, a.ldr = 0;
     a.relu_cols = cout_a;
-    a.ntaps = 1, a.cpt = tin.Cs / 32, a.K = tin.Cs;
+    a.ntaps = 1, a.cpt = tin.Cs / EPR, a.K = tin.Cs;
+    a.bf16 = h->bf16;
     L.Nreal = cout_a + cout_b, L.Kreal = cin;
     a.Nvalid = L.Nreal;
     L.flops = 2.0 * a.M * (double)cin * L.Nreal;
@@ -453,7 +493,7 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     }
     for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
     for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
-    if (upload(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
+    if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
     h->layers.push_back(L);
     *shortcut = L.out2;
     return L.out;
@@ -563,13 +603,15 @@ int finalize_impl(vnect_handle* h)
         if (!W1 || !W2 || !ga || !be || !mu || !va) return VNECT_E_ARG;
         Layer L;
         L.op = OP_CONV, L.name = "res5c_deconv", L.in = r;
-        feat = L.out = add_tensor(h, "res5c_branch2a_feat", S, 2 * tin.H, 2 * tin.W, 212, 224);
+        const int featCs = h->bf16 ? 256 : 224;  // 212 channels padded to a whole number of K chunks
+        feat = L.out = add_tensor(h, "res5c_branch2a_feat", S, 2 * tin.H, 2 * tin.W, 212, featCs);
         ConvArgs& a = L.a;
         a.S = S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
         a.Ho = tin.H, a.Wo = tin.W, a.M = S * tin.H * tin.W;
         a.stride = 1, a.OH = 2 * tin.H, a.OW = 2 * tin.W, a.os = 2, a.nphase = 4;
-        a.ntaps = 4, a.cpt = tin.Cs / 32, a.K = 4 * tin.Cs;
-        a.ldc = 224, a.ldr = 0, a.relu_cols = 128, a.Nvalid = 191;
+        a.ntaps = 4, a.cpt = tin.Cs / (h->bf16 ? 64 : 32), a.K = 4 * tin.Cs;
+        a.bf16 = h->bf16;
+        a.ldc = featCs, a.ldr = 0, a.relu_cols = 128, a.Nvalid = 191;
         L.Nreal = 191, L.Kreal = 4 * 256;
         L.flops = 2.0 * (double)S * 46 * 46 * 4 * 256 * 191;
         choose_tile(L, (long long)S * 46 * 46);
@@ -599,7 +641,7 @@ int finalize_impl(vnect_handle* h)
             sc[c] = ga->d[c] * (1.0f / sqrtf(va->d[c] + 0.001f));
             sh[c] = be->d[c];
         }
-        if (upload(h, &L.w, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
+        if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
             return VNECT_E_HIP;
         h->layers.push_back(L);
         Layer Bn;
@@ -624,9 +666,11 @@ int finalize_impl(vnect_handle* h)
 #undef NEED
     // buffers
     for (Tensor& t : h->tensors) {
-        int rc = dev_alloc(h, &t.d, t.floats());
+        char* p = nullptr;
+        int rc = dev_alloc(h, &p, t.bytes());
         if (rc) return rc;
-        HIPCK(h, hipMemset(t.d, 0, t.floats() * sizeof(float)));
+        t.d = (float*)p;
+        HIPCK(h, hipMemset(t.d, 0, t.bytes()));
     }
     size_t ws = 0;
     for (Layer& L : h->layers)
@@ -656,6 +700,7 @@ int finalize_impl(vnect_handle* h)
             q.ws = h->ws, q.bias = L.bias, q.scale = L.scale, q.shift = L.shift, q.resid = a.resid, q.out = a.out;
             q.npix = (long long)a.S * a.OH * a.OW, q.Npad = a.Npad, q.Nvalid = a.Nvalid, q.ldc = a.ldc, q.ldr = a.ldr;
             q.ksplit = a.ksplit, q.relu_cols = a.relu_cols;
+            q.bf16 = a.bf16, q.out_f32 = a.out_f32;
         }
         h->conv_flops += L.flops;
         h->conv_launches += 1;
@@ -674,10 +719,10 @@ int run_network(vnect_handle* h, bool timed)
             if (L.a.ksplit > 1) HIPCK(h, launch_reduce(L.r, h->st));
         } else if (L.op == OP_POOL) {
             const Tensor &i = h->tensors[L.in], &o = h->tensors[L.out];
-            HIPCK(h, launch_maxpool(i.d, o.d, i.S, i.H, i.W, i.Cs, o.H, o.W, h->st));
+            HIPCK(h, launch_maxpool(i.d, o.d, i.S, i.H, i.W, i.Cs, o.H, o.W, h->bf16, h->st));
         } else {
             const Tensor& t = h->tensors[L.out];
-            HIPCK(h, launch_bone(t.d, (long long)t.S * t.H * t.W, t.Cs, h->st));
+            HIPCK(h, launch_bone(t.d, (long long)t.S * t.H * t.W, t.Cs, h->bf16, h->st));
         }
     }
     return VNECT_OK;
@@ -687,7 +732,7 @@ int run_pre(vnect_handle* h)
 {
     HIPCK(h, launch_squarify(h->d_fp, h->sq, h->st));
     HIPCK(h, launch_pyramid(h->sq, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
-                            h->sharded ? h->cfg.pyramid_rank : 0, h->st));
+                            h->sharded ? h->cfg.pyramid_rank : 0, h->bf16, h->st));
     return VNECT_OK;
 }
 
@@ -905,8 +950,8 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         return fail(nullptr, VNECT_E_ARG, "vnect_create: bad config (struct_size mismatch)");
     if (cfg->num_scales < 1 || cfg->num_scales > VNECT_MAX_SCALES)
         return fail(nullptr, VNECT_E_ARG, "vnect_create: num_scales out of range");
-    if (cfg->precision != VNECT_FP32)
-        return fail(nullptr, VNECT_E_ARG, "vnect_create: only VNECT_FP32 is built in this round");
+    if (cfg->precision != VNECT_FP32 && cfg->precision != VNECT_BF16)
+        return fail(nullptr, VNECT_E_ARG, "vnect_create: precision must be VNECT_FP32 or VNECT_BF16");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
         return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: no HIP device " + std::to_string(cfg->device));
@@ -920,6 +965,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     h->cfg = *cfg;
     h->S = cfg->num_scales;
     h->Snet = sharded ? 1 : cfg->num_scales;
+    h->bf16 = cfg->precision == VNECT_BF16;
     h->sharded = sharded;
     if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
     if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
@@ -1044,11 +1090,11 @@ int vnect_forward(vnect_handle* h, const float* batch, int num_images, float* ou
     HIPCK(h, hipSetDevice(h->cfg.device));
     const long long npix = (long long)h->Snet * BOX * BOX;
     HIPCK(h, hipMemcpyAsync(h->in3, batch, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->st));
-    HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->st));
+    HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->bf16, h->st));
     int rc = run_network(h, false);
     if (rc) return rc;
     const Tensor& t = h->tensors[h->t_out];
-    HIPCK(h, hipMemcpyAsync(out, t.d, t.floats() * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    HIPCK(h, hipMemcpyAsync(out, t.d, t.bytes(), hipMemcpyDeviceToHost, h->st));
     HIPCK(h, hipStreamSynchronize(h->st));
     return VNECT_OK;
 }
@@ -1070,7 +1116,7 @@ int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t 
     if ((rc = run_pre(h))) return rc;
     if (batch_out) {
         const long long npix = (long long)h->Snet * BOX * BOX;
-        HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->st));
+        HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->bf16, h->st));
         HIPCK(h, hipMemcpyAsync(batch_out, h->in3, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->st));
     }
     HIPCK(h, hipStreamSynchronize(h->st));
@@ -1170,8 +1216,14 @@ int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t
     if ((int64_t)(npix * t.C) > capacity) return fail(h, VNECT_E_ARG, "vnect_read_activation: capacity too small");
     HIPCK(h, hipSetDevice(h->cfg.device));
     HIPCK(h, hipStreamSynchronize(h->st));
-    HIPCK(h, hipMemcpy2D(out, (size_t)t.C * sizeof(float), t.d, (size_t)t.Cs * sizeof(float), (size_t)t.C * sizeof(float),
-                         npix, hipMemcpyDeviceToHost));
+    if (t.esz == 4) {
+        HIPCK(h, hipMemcpy2D(out, (size_t)t.C * sizeof(float), t.d, (size_t)t.Cs * sizeof(float), (size_t)t.C * sizeof(float),
+                             npix, hipMemcpyDeviceToHost));
+    } else {  // bf16 activations: fetch raw, widen on the host
+        std::vector<uint16_t> raw(npix * t.C);
+        HIPCK(h, hipMemcpy2D(raw.data(), (size_t)t.C * 2, t.d, (size_t)t.Cs * 2, (size_t)t.C * 2, npix, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < raw.size(); i++) out[i] = from_bf16(raw[i]);
+    }
     return VNECT_OK;
 }
 
