@@ -443,7 +443,7 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
     if (a.Npad % BN != 0 || a.K != a.ntaps * a.cpt * epr || a.nphase * a.ntaps > MAX_TAPS ||
         a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || !a.zeros || (a.bf16 && a.out2 && a.split_n % 64))
         return hipErrorInvalidValue;
-    if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);
+    if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);  // a 3-stage ring (3 workgroups per CU) was measured: no gain
     if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
     if (BM == 64 && BN == 128) return launch_g<64, 128, 3>(a, st);
     return hipErrorInvalidValue;

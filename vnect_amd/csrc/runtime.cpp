@@ -366,7 +366,11 @@ void choose_tile(Layer& L, long long npix)
     const int kel = L.a.K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
     int BM = 64, BN = 64, ks = 1;
     const long long tiles = (long long)((L.a.M + 63) / 64) * (round_up(L.Nreal, 64) / 64) * L.a.nphase;
-    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) ks = std::min(5, nch);
+    if (L.a.bf16) {  // bf16 loops are 2-3x shorter: the extra reduce launch only pays for the smallest, deepest layer
+        if (tiles <= 64 && kel >= 2048) ks = std::min(5, nch);
+    } else if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
+        ks = std::min(5, nch);
+    }
     const char* force = getenv("VNECT_FORCE_TILE");
     if (force) {
         int fBM = 0, fBN = 0, fks = 0;
