@@ -33,7 +33,7 @@ if st:
     calls = sum(int(r["Calls"]) for r in conv)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in conv)
     allk = sum(float(r["TotalDurationNs"]) for r in rows)
-    sq = [r for r in rows if "squarify" in r["Name"]]
+    sq = [r for r in rows if "pyramid_kernel" in r["Name"]]
     frames = int(sq[0]["Calls"]) if sq else 0
     res["frames_profiled"] = frames
     res["conv_kernel"] = conv[0]["Name"] if conv else None

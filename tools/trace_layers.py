@@ -19,8 +19,8 @@ for r in rows:
 print("%-70s %8s %10s %9s" % ("kernel", "calls", "total_us", "avg_us"))
 for k, (d, n) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
     print("%-70s %8d %10.1f %9.2f" % (k[:70], n, d / 1e3, d / n / 1e3))
-# frame segmentation: a frame starts at squarify_kernel
-starts = [i for i, r in enumerate(rows) if "squarify" in r["Kernel_Name"]]
+# frame segmentation: a frame starts at pyramid_kernel
+starts = [i for i, r in enumerate(rows) if "pyramid_kernel" in r["Kernel_Name"]]
 if len(starts) >= 3:
     a, b = starts[-2], starts[-1]
     fr = rows[a:b]

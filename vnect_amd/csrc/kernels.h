@@ -9,9 +9,8 @@ constexpr int BOX = 368;
 constexpr int HM = 46;
 constexpr int NJ = 21;
 constexpr int MAPC = 84;       // 4 maps x 21 joints
-constexpr int ARG_SLABS = 8;   // row slabs per joint in the arg-max kernel (368 / 8 = 46 rows each)
-constexpr int ARG_XBLOCKS = 3; // 128-column blocks per slab
 constexpr int MAX_TAPS = 16;
+constexpr int ARG_SLABS = 8;    // arg-max workgroups per joint (6 row segments each)
 constexpr int PROF_SLOTS = 16;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
@@ -95,8 +94,7 @@ struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.
     float lut[256]; // (float)v / 255 - 0.4 in float32
 };
 
-hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st);
-hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
+hipError_t launch_pyramid(const FrameParams* fp, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
 // ---- post-processing ------------------------------------------------------------------
 struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale
@@ -137,9 +135,9 @@ struct JointsOut {
     int status;
 };
 
-hipError_t launch_merge(const float* maps, const MergeTabs* tabs, double* avg, int S, hipStream_t st);
-hipError_t launch_argmax(const double* avg, const UpTab* up, ArgPartial* part, hipStream_t st);
-hipError_t launch_joints(const ArgPartial* part, const double* avg, FilterBank* fb, const FrameParams* fp, int nep50,
-                         JointsOut* out, hipStream_t st);
+hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, double* hm, ArgPartial* part,
+                         hipStream_t st);
+hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
+                         const FrameParams* fp, int nep50, JointsOut* out, hipStream_t st);
 
 }  // namespace vnect

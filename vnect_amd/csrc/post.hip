@@ -4,59 +4,68 @@
 // src/utils.py:13-21,58-79,153-219 and src/OneEuroFilter.py:13-75, so results are bit-identical to it.
 #include "kernels.h"
 
+#include <stddef.h>
+
 namespace vnect {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int VNECT_MAX_S = 8;  // VNECT_MAX_SCALES
 
 // ---------------------------------------------------------------------------------------------
 // 8-bit bilinear sample, OpenCV fixed-point form (HResizeLinear<uchar,int,short,2048> then
-// VResizeLinear<uchar,...,FixedPtCast<int,uchar,22>>): src rows are `pitch` bytes apart, 3 channels.
-__device__ __forceinline__ void sample_u8x3(const uint8_t* src, long long pitch, const ResizeTab& t, int dy, int dx,
-                                            int out[3])
+// VResizeLinear<uchar,...,FixedPtCast<int,uchar,22>>).  `px(row, col, v)` yields the 3 channels of a source pixel.
+template <typename Px>
+__device__ __forceinline__ void sample_u8x3(Px px, const ResizeTab& t, int dy, int dx, int out[3])
 {
-    const uint8_t* S0 = src + (long long)t.sy0[dy] * pitch;
-    const uint8_t* S1 = src + (long long)t.sy1[dy] * pitch;
-    const int sx = t.sx[dx] * 3;
+    const int r0y = t.sy0[dy], r1y = t.sy1[dy];
+    const int sx = t.sx[dx];
     const int b0 = t.b0[dy], b1 = t.b1[dy];
     const bool inner = dx < t.xmax;
     const int a0 = t.a0[dx], a1 = t.a1[dx];
+    int p00[3], p01[3] = {0, 0, 0}, p10[3], p11[3] = {0, 0, 0};
+    px(r0y, sx, p00);
+    px(r1y, sx, p10);
+    if (inner) {
+        px(r0y, sx + 1, p01);
+        px(r1y, sx + 1, p11);
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         int r0, r1;
         if (inner) {
-            r0 = S0[sx + c] * a0 + S0[sx + 3 + c] * a1;
-            r1 = S1[sx + c] * a0 + S1[sx + 3 + c] * a1;
+            r0 = p00[c] * a0 + p01[c] * a1;
+            r1 = p10[c] * a0 + p11[c] * a1;
         } else {
-            r0 = S0[sx + c] * 2048;
-            r1 = S1[sx + c] * 2048;
+            r0 = p00[c] * 2048;
+            r1 = p10[c] * 2048;
         }
         out[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
     }
 }
 
-// utils.img_scale_squarify + img_padding (utils.py:82-120): frame (H,W,3) u8 -> 368x368x3 u8 canvas
-__global__ void squarify_kernel(const FrameParams* __restrict__ fp, uint8_t* __restrict__ sq)
+// utils.img_scale_squarify + img_padding (utils.py:82-120): pixel (y, x) of the 368x368 canvas, computed from the
+// frame on demand (the canvas itself is never materialised)
+__device__ __forceinline__ void square_pixel(const FrameParams* __restrict__ fp, int y, int x, int v[3])
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= BOX) return;
     const ResizeTab& t = fp->sq;
     const int dy = y - fp->offy, dx = x - fp->offx;
-    int v[3] = {0, 0, 0};
+    v[0] = v[1] = v[2] = 0;
     if (dy >= 0 && dy < t.dh && dx >= 0 && dx < t.dw) {
-        if (t.copy) {
-            const uint8_t* p = fp->frame + (long long)dy * fp->row_stride + dx * 3;
-            v[0] = p[0], v[1] = p[1], v[2] = p[2];
-        } else {
-            sample_u8x3(fp->frame, fp->row_stride, t, dy, dx, v);
-        }
+        const uint8_t* frame = fp->frame;
+        const long long pitch = fp->row_stride;
+        auto fpx = [&](int r, int c, int* o) {
+            const uint8_t* p = frame + (long long)r * pitch + c * 3;
+            o[0] = p[0], o[1] = p[1], o[2] = p[2];
+        };
+        if (t.copy) fpx(dy, dx, v);
+        else sample_u8x3(fpx, t, dy, dx, v);
     }
-    uint8_t* o = sq + ((long long)y * BOX + x) * 3;
-    o[0] = (uint8_t)v[0], o[1] = (uint8_t)v[1], o[2] = (uint8_t)v[2];
 }
 
-// utils.img_scale_padding per scale + `/255 - 0.4` (estimator.py:76-80) -> (S,368,368,4) f32, 4th = 0
+// gen_input_batch in one kernel (estimator.py:70-81): squarify, utils.img_scale_padding per scale (each stage rounds
+// to uint8 exactly like the two cv2.resize calls of the reference) and `/255 - 0.4` -> (S,368,368,4), 4th channel 0
 template <typename T>
-__global__ void pyramid_kernel(const uint8_t* __restrict__ sq, const ScaleTabs* __restrict__ tabs,
+__global__ void pyramid_kernel(const FrameParams* __restrict__ fp, const ScaleTabs* __restrict__ tabs,
                                T* __restrict__ batch4, int scale_base)
 {
     typedef T tx4 __attribute__((ext_vector_type(4)));
@@ -65,142 +74,155 @@ __global__ void pyramid_kernel(const uint8_t* __restrict__ sq, const ScaleTabs* 
     if (x >= BOX) return;
     int v[3] = {0, 0, 0};
     if (!tabs->scaled[s]) {
-        const uint8_t* p = sq + ((long long)y * BOX + x) * 3;
-        v[0] = p[0], v[1] = p[1], v[2] = p[2];
+        square_pixel(fp, y, x, v);
     } else {
         const ResizeTab& t = tabs->t[s];
         const int dy = y - tabs->pad[s], dx = x - tabs->pad[s];
         if (dy >= 0 && dy < t.dh && dx >= 0 && dx < t.dw) {
-            if (t.copy) {
-                const uint8_t* p = sq + ((long long)dy * BOX + dx) * 3;
-                v[0] = p[0], v[1] = p[1], v[2] = p[2];
-            } else {
-                sample_u8x3(sq, (long long)BOX * 3, t, dy, dx, v);
-            }
+            auto spx = [&](int r, int c, int* o) { square_pixel(fp, r, c, o); };
+            if (t.copy) spx(dy, dx, v);
+            else sample_u8x3(spx, t, dy, dx, v);
         }
     }
     f32x4 o = {tabs->lut[v[0]], tabs->lut[v[1]], tabs->lut[v[2]], 0.f};
     *(tx4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4) = __builtin_convertvector(o, tx4);
 }
 
-hipError_t launch_squarify(const FrameParams* fp, uint8_t* sq, hipStream_t st)
-{
-    hipLaunchKernelGGL(squarify_kernel, dim3((BOX + 127) / 128, BOX), dim3(128), 0, st, fp, sq);
-    return hipGetLastError();
-}
-hipError_t launch_pyramid(const uint8_t* sq, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st)
+hipError_t launch_pyramid(const FrameParams* fp, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st)
 {
     dim3 g((BOX + 127) / 128, BOX, S);
-    if (bf16) hipLaunchKernelGGL(pyramid_kernel<__bf16>, g, dim3(128), 0, st, sq, tabs, (__bf16*)batch4, scale_base);
-    else hipLaunchKernelGGL(pyramid_kernel<float>, g, dim3(128), 0, st, sq, tabs, (float*)batch4, scale_base);
+    if (bf16) hipLaunchKernelGGL(pyramid_kernel<__bf16>, g, dim3(128), 0, st, fp, tabs, (__bf16*)batch4, scale_base);
+    else hipLaunchKernelGGL(pyramid_kernel<float>, g, dim3(128), 0, st, fp, tabs, (float*)batch4, scale_base);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// estimator.py:105-129: avg[q][r][c][j] = (1/S) * sum_i crop(cv2.resize(map_i_q, 1/s_i))[r][c][j], f64 sum
-__global__ void merge_kernel(const float* __restrict__ maps, const MergeTabs* __restrict__ tabs,
-                             double* __restrict__ avg, int S)
+// estimator.py:105-129: one cell of a merged map,
+//   avg_q[r][c][j] = (1/S) * sum_i crop(cv2.resize(map_i_q, fx=fy=1/s_i))[r][c][j]   (f32 interpolation, f64 sum)
+// evaluated on demand: the four 46x46x21 f64 averages of the reference are never materialised.
+__device__ __forceinline__ double merged_cell(const float* __restrict__ maps, const MergeTabs* __restrict__ tabs, int S,
+                                              int ch, int r, int c)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 4 * HM * HM * NJ) return;
-    const int j = idx % NJ;
-    int t = idx / NJ;
-    const int c = t % HM;
-    t /= HM;
-    const int r = t % HM, q = t / HM;
-    const int ch = q * NJ + j;
-    double acc = 0.0;
-    for (int i = 0; i < S; i++) {
-        const MergeTab& mt = tabs->t[i];
-        const float* M = maps + (long long)i * HM * HM * MAPC + ch;
-        float v;
-        if (mt.copy) {
-            v = M[(r * HM + c) * MAPC];
-        } else {
-            const int sx = mt.sx[c];
+    // All taps of all scales are requested before any is used (no load sits behind a data-dependent branch), so a
+    // thread pays one memory round trip, not one per scale.  For a scale that is a plain copy (size unchanged) the
+    // tables are the identity: tap (sy0[r], sx[c]) IS element (r, c).
+    float p00[VNECT_MAX_S], p01[VNECT_MAX_S], p10[VNECT_MAX_S], p11[VNECT_MAX_S];
+#pragma unroll
+    for (int i = 0; i < VNECT_MAX_S; i++) {
+        if (i < S) {
+            const MergeTab& mt = tabs->t[i];
+            const float* M = maps + (long long)i * HM * HM * MAPC + ch;
+            const int sx = mt.sx[c], sx1 = sx + 1 < HM ? sx + 1 : HM - 1;
             const float* R0 = M + (long long)mt.sy0[r] * HM * MAPC;
             const float* R1 = M + (long long)mt.sy1[r] * HM * MAPC;
-            float r0, r1;
-            if (mt.edge[c]) {
-                r0 = R0[sx * MAPC];
-                r1 = R1[sx * MAPC];
-            } else {
-                const float a0 = mt.a0[c], a1 = mt.a1[c];
-                r0 = R0[sx * MAPC] * a0 + R0[(sx + 1) * MAPC] * a1;
-                r1 = R1[sx * MAPC] * a0 + R1[(sx + 1) * MAPC] * a1;
-            }
-            v = r0 * mt.b0[r] + r1 * mt.b1[r];
+            p00[i] = R0[sx * MAPC], p01[i] = R0[sx1 * MAPC], p10[i] = R1[sx * MAPC], p11[i] = R1[sx1 * MAPC];
         }
-        acc += (double)v;
     }
-    avg[idx] = acc / (double)S;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < VNECT_MAX_S; i++) {
+        if (i < S) {
+            const MergeTab& mt = tabs->t[i];
+            const float a0 = mt.a0[c], a1 = mt.a1[c];
+            const float r0 = mt.edge[c] ? p00[i] : p00[i] * a0 + p01[i] * a1;
+            const float r1 = mt.edge[c] ? p10[i] : p10[i] * a0 + p11[i] * a1;
+            const float v = mt.copy ? p00[i] : r0 * mt.b0[r] + r1 * mt.b1[r];
+            acc += (double)v;
+        }
+    }
+    return acc / (double)S;
 }
-hipError_t launch_merge(const float* maps, const MergeTabs* tabs, double* avg, int S, hipStream_t st)
+
+// Merged heat-maps only (map 0 of estimator.py:105-129), written joint-major [j][r][c] so that the arg-max workgroup
+// of a joint reads one contiguous 46x46 plane.  Threads run channel-fastest: the NHWC reads are 84-byte runs.
+__global__ __launch_bounds__(256) void merge_heat_kernel(const float* __restrict__ maps, const MergeTabs* __restrict__ tabs,
+                                                         int S, double* __restrict__ hm)
 {
-    const int total = 4 * HM * HM * NJ;
-    hipLaunchKernelGGL(merge_kernel, dim3((total + 255) / 256), dim3(256), 0, st, maps, tabs, avg, S);
-    return hipGetLastError();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= HM * HM * NJ) return;
+    const int j = idx % NJ, p = idx / NJ;
+    hm[j * (HM * HM) + p] = merged_cell(maps, tabs, S, j, p / HM, p % HM);
+}
+
+// the merge tables are read many times per thread: copy them to LDS once per workgroup
+__device__ __forceinline__ void stage_merge_tabs(const MergeTabs* __restrict__ g, MergeTabs* l, int S)
+{
+    const int words = (int)((offsetof(MergeTabs, t) + sizeof(MergeTab) * S) / 4);
+    const int* src = (const int*)g;
+    int* dst = (int*)l;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------
-// utils.extract_2d_joints (utils.py:153-175) without materialising the 368x368 upsample: every
-// thread evaluates cv2's f64 bilinear at its pixels and keeps (max value, lowest flat index).
+// utils.extract_2d_joints (utils.py:153-175) for one joint per workgroup, without materialising the 368x368 f64
+// upsample (22.7 MB per frame in the reference): the merged heat-map of the joint is copied to LDS, then one thread per
+// (column x, half of the rows) evaluates cv2's separable f64 bilinear -- the horizontal pass h(sy) = M[sy][sx]*a0 +
+// M[sy][sx+1]*a1 once per source row, reused by the destination rows that blend it, exactly as resize.cpp does --
+// and keeps (max value, lowest flat index) = np.argmax's first maximum.
 __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-// One thread = one column x of the virtual 368x368 upsample, for one 46-row slab of one joint.  cv2's resize is
-// separable: the horizontal pass h(sy) = M[sy][sx]*a0 + M[sy][sx+1]*a1 is evaluated once per source row and
-// reused by the (up to 8) destination rows that blend it, exactly as resize.cpp does it.
-__global__ __launch_bounds__(128) void argmax_kernel(const double* __restrict__ avg, const UpTab* __restrict__ up,
-                                                     ArgPartial* __restrict__ part)
+constexpr int ARG_THREADS = 384;  // one thread per column (368 used)
+constexpr int ARG_SEGS = 6;       // 8-row segments per workgroup: 8 slabs x 6 >= 47 segments, 168 workgroups keep the f64 work off one CU
+
+__global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const double* __restrict__ hm,
+                                                                  const UpTab* __restrict__ up,
+                                                                  ArgPartial* __restrict__ part)
 {
     __shared__ double map[HM * HM];
-    __shared__ double sv[128];
-    __shared__ int si[128];
-    const int j = blockIdx.x, slab = blockIdx.y, xb = blockIdx.z, tid = threadIdx.x;
-    for (int p = tid; p < HM * HM; p += 128) map[p] = avg[(long long)p * NJ + j];  // heatmap = avg[0]
+    __shared__ double sv[ARG_THREADS];
+    __shared__ int si[ARG_THREADS];
+    __shared__ double tb0[16], tb1[16];  // the 8 row phases (rows 4..11 of the table)
+    const int j = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
+    if (tid < 16) tb0[tid] = up->b0[tid], tb1[tid] = up->b1[tid];
+    for (int p = tid; p < HM * HM; p += ARG_THREADS) map[p] = hm[j * (HM * HM) + p];
     __syncthreads();
-    constexpr int ROWS = BOX / ARG_SLABS;
-    const int x = xb * 128 + tid;
+    // Row structure of the x8 upsample (checked against the table on the host, build_up_table): destination row y
+    // belongs to segment g = (y + 4) / 8 and phase p = (y + 4) % 8; it blends source rows max(g-1, 0) and min(g, 45)
+    // with weights b0[4 + p], b1[4 + p].  Segment 0 has phases 4..7 (rows 0..3), segment 46 phases 0..3 (rows 364..367).
+    const int x = tid;
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
     if (x < BOX) {
         const int sx = up->sx[x], edge = up->edge[x];
         const double a0 = up->a0[x], a1 = up->a1[x];
+        double w0[8], w1[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) w0[p] = tb0[4 + p], w1[p] = tb1[4 + p];
         auto hrow = [&](int sy) {
             const double* R = map + sy * HM;
             return edge ? R[sx] : R[sx] * a0 + R[sx + 1] * a1;
         };
-        int c0 = -1, c1 = -1;
-        double h0 = 0, h1 = 0;
-        for (int y = slab * ROWS; y < (slab + 1) * ROWS; y++) {
-            const int s0 = up->sy0[y], s1 = up->sy1[y];  // uniform over the block
-            if (s0 != c0) {
-                h0 = s0 == c1 ? h1 : hrow(s0);
-                c0 = s0;
+        const int g0 = slab * ARG_SEGS, g1 = g0 + ARG_SEGS < 47 ? g0 + ARG_SEGS : 47;
+        double h1 = hrow(g0 > 0 ? g0 - 1 : 0);
+        for (int g = g0; g < g1; g++) {
+            const double h0 = h1;
+            h1 = hrow(g < HM ? g : HM - 1);
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int y = g * 8 - 4 + p;
+                const double v = h0 * w0[p] + h1 * w1[p];
+                if (y >= 0 && y < BOX && v > bv) bv = v, bi = y * BOX + x;  // rows ascend: strict > keeps the first maximum
             }
-            if (s1 != c1) {
-                h1 = s1 == c0 ? h0 : hrow(s1);
-                c1 = s1;
-            }
-            const double v = h0 * up->b0[y] + h1 * up->b1[y];
-            if (v > bv) bv = v, bi = y * BOX + x;  // rows ascend: strict > keeps the first maximum of this column
         }
     }
     sv[tid] = bv, si[tid] = bi;
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
+    if (tid < 128 && better(sv[tid + 256], si[tid + 256], sv[tid], si[tid])) sv[tid] = sv[tid + 256], si[tid] = si[tid + 256];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s && better(sv[tid + s], si[tid + s], sv[tid], si[tid])) sv[tid] = sv[tid + s], si[tid] = si[tid + s];
         __syncthreads();
     }
     if (tid == 0) {
-        ArgPartial& o = part[(j * ARG_SLABS + slab) * ARG_XBLOCKS + xb];
-        o.v = sv[0];
-        o.idx = si[0];
+        part[j * ARG_SLABS + slab].v = sv[0];
+        part[j * ARG_SLABS + slab].idx = si[0];
     }
 }
-hipError_t launch_argmax(const double* avg, const UpTab* up, ArgPartial* part, hipStream_t st)
+hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, double* hm, ArgPartial* part,
+                         hipStream_t st)
 {
-    hipLaunchKernelGGL(argmax_kernel, dim3(NJ, ARG_SLABS, ARG_XBLOCKS), dim3(128), 0, st, avg, up, part);
+    hipLaunchKernelGGL(merge_heat_kernel, dim3((HM * HM * NJ + 255) / 256), dim3(256), 0, st, maps, mtabs, S, hm);
+    hipLaunchKernelGGL(heat_argmax_kernel, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, hm, up, part);
     return hipGetLastError();
 }
 
@@ -266,8 +288,9 @@ __device__ float oef_f32(Filt& f, float x, double t, int nep50)
     return r;
 }
 
-// utils.hm_pt_interp_bilinear (utils.py:58-79), scale 8, map element (r,c) at m[(r*46+c)*21]
-__device__ double pt_interp(const double* m, double dst_y, double dst_x)
+// utils.hm_pt_interp_bilinear (utils.py:58-79), scale 8, on merged map q (channel ch) evaluated cell by cell
+__device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S, int ch,
+                            double dst_y, double dst_x)
 {
     const double src_x = (dst_x + 0.5) / 8.0 - 0.5;
     const double src_y = (dst_y + 0.5) / 8.0 - 0.5;
@@ -276,54 +299,63 @@ __device__ double pt_interp(const double* m, double dst_y, double dst_x)
     y0 = y0 < 0 ? 0 : (y0 > HM - 1 ? HM - 1 : y0);  // keep NaN inputs from indexing outside the map
     const int x1 = x0 + 1 < HM - 1 ? x0 + 1 : HM - 1;
     const int y1 = y0 + 1 < HM - 1 ? y0 + 1 : HM - 1;
-    const double v0 = (x1 - src_x) * m[(y0 * HM + x0) * NJ] + (src_x - x0) * m[(y0 * HM + x1) * NJ];
-    const double v1 = (x1 - src_x) * m[(y1 * HM + x0) * NJ] + (src_x - x0) * m[(y1 * HM + x1) * NJ];
+    const double m00 = merged_cell(maps, mtabs, S, ch, y0, x0), m01 = merged_cell(maps, mtabs, S, ch, y0, x1);
+    const double m10 = merged_cell(maps, mtabs, S, ch, y1, x0), m11 = merged_cell(maps, mtabs, S, ch, y1, x1);
+    const double v0 = (x1 - src_x) * m00 + (src_x - x0) * m01;
+    const double v1 = (x1 - src_x) * m10 + (src_x - x0) * m11;
     return (y1 - src_y) * v0 + (src_y - y0) * v1;
 }
 
-// estimator.py:132-139 for all 21 joints: arg-max finish, 2-D filter, read-off, root, 3-D filter, un-map
-__global__ __launch_bounds__(64) void joints_kernel(const ArgPartial* __restrict__ part, const double* __restrict__ avg,
-                                                    FilterBank* fb, const FrameParams* __restrict__ fp, int nep50,
-                                                    JointsOut* __restrict__ out)
+// estimator.py:132-139 for all 21 joints in one workgroup, one thread per filter: 42 2-D filters, then 63 read-offs
+// (x/y/z maps merged on demand) + root subtraction + 63 3-D filters, then the un-mapping.
+__global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
+                                                     const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
+                                                     const FrameParams* __restrict__ fp, int nep50,
+                                                     JointsOut* __restrict__ out)
 {
-    __shared__ float root[3];
-    const int j = threadIdx.x;
-    const bool live = j < NJ;
-    float p3[3] = {0.f, 0.f, 0.f};
-    double row = 0, col = 0;
-    if (live) {
-        constexpr int NP = ARG_SLABS * ARG_XBLOCKS;
-        double bv = part[j * NP].v;
-        int bi = part[j * NP].idx;
-        for (int s = 1; s < NP; s++) {
-            const double v = part[j * NP + s].v;
-            const int i = part[j * NP + s].idx;
-            if (better(v, i, bv, bi)) bv = v, bi = i;
-        }
+    __shared__ double c2[NJ * 2];
+    __shared__ float p3[NJ * 3];
+    __shared__ MergeTabs smt;
+    const int t = threadIdx.x;
+    // Every global read that does not depend on a computed value is requested up front (tables, partials, both
+    // filter states, frame parameters): the kernel is one workgroup and is priced in memory round trips.
+    stage_merge_tabs(mtabs, &smt, S);  // visible after the barrier below
+    const int j2 = t < NJ * 2 ? t >> 1 : 0, k2 = t & 1;
+    const int j3 = t < NJ * 3 ? t / 3 : 0, k3 = t < NJ * 3 ? t - 3 * j3 : 0;
+    Filt f2 = fb->f2[j2][k2];
+    Filt f3 = fb->f3[j3][k3];
+    const double t2d = fp->t2d, t3d = fp->t3d, scaler = fp->scaler;
+    const double off = k2 == 0 ? (double)fp->offy : (double)fp->offx;
+    double pv[ARG_SLABS];
+    int pi[ARG_SLABS];
+#pragma unroll
+    for (int s = 0; s < ARG_SLABS; s++) pv[s] = part[j2 * ARG_SLABS + s].v, pi[s] = part[j2 * ARG_SLABS + s].idx;
+    if (t < NJ * 2) {
+        double bv = pv[0];
+        int bi = pi[0];
+#pragma unroll
+        for (int s = 1; s < ARG_SLABS; s++)  // slabs ascend in row order
+            if (better(pv[s], pi[s], bv, bi)) bv = pv[s], bi = pi[s];
         if (bi == 0x7fffffff) bi = 0;  // all-NaN map: np.argmax would return the first NaN; documented deviation
-        row = (double)(bi / BOX), col = (double)(bi % BOX);
-        row = oef_f64(fb->f2[j][0], row, fp->t2d);
-        col = oef_f64(fb->f2[j][1], col, fp->t2d);
-        const long long P = (long long)HM * HM * NJ;
-        for (int k = 0; k < 3; k++) p3[k] = (float)(pt_interp(avg + (k + 1) * P + j, row, col) * 100);
-        if (j == 14) root[0] = p3[0], root[1] = p3[1], root[2] = p3[2];
+        const double raw = k2 == 0 ? (double)(bi / BOX) : (double)(bi % BOX);  // [row, col]
+        c2[t] = oef_f64(f2, raw, t2d);
+        fb->f2[j2][k2] = f2;
     }
     __syncthreads();
-    if (live) {
-        for (int k = 0; k < 3; k++) {
-            float v = p3[k] - root[k];  // joints_3d -= joints_3d[14, :] in float32
-            v = oef_f32(fb->f3[j][k], v, fp->t3d, nep50);
-            out->j3d[j * 3 + k] = v;
-        }
-        out->j2d[j * 2 + 0] = (row - fp->offy) / fp->scaler;
-        out->j2d[j * 2 + 1] = (col - fp->offx) / fp->scaler;
+    if (t < NJ * 3) p3[t] = (float)(pt_interp(maps, &smt, S, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
+    __syncthreads();
+    if (t < NJ * 3) {
+        const float v = p3[t] - p3[14 * 3 + k3];  // joints_3d -= joints_3d[14, :] in float32
+        out->j3d[t] = oef_f32(f3, v, t3d, nep50);
+        fb->f3[j3][k3] = f3;
     }
-    if (j == 0) out->status = 0;
+    if (t < NJ * 2) out->j2d[t] = (c2[t] - off) / scaler;
+    if (t == 0) out->status = 0;
 }
-hipError_t launch_joints(const ArgPartial* part, const double* avg, FilterBank* fb, const FrameParams* fp, int nep50,
-                         JointsOut* out, hipStream_t st)
+hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
+                         const FrameParams* fp, int nep50, JointsOut* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(joints_kernel, dim3(1), dim3(64), 0, st, part, avg, fb, fp, nep50, out);
+    hipLaunchKernelGGL(joints_kernel, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, nep50, out);
     return hipGetLastError();
 }
 

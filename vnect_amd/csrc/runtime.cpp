@@ -75,14 +75,13 @@ struct vnect_handle {
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; };
     std::vector<SlotInfo> slots;
-    uint8_t* sq = nullptr;
     FrameParams* d_fp = nullptr;
     FrameParams* h_fp[RING] = {};  // pinned
     ScaleTabs* d_stabs = nullptr;
     MergeTabs* d_mtabs = nullptr;
     UpTab* d_up = nullptr;
-    double* d_avg = nullptr;
     ArgPartial* d_part = nullptr;
+    double* d_hm = nullptr;  // merged heat-maps, joint-major (21,46,46) f64
     FilterBank* d_fb = nullptr;
     JointsOut* d_out = nullptr;
     JointsOut* h_out[RING] = {};  // pinned
@@ -294,6 +293,13 @@ int build_up_table(vnect_handle* h)
         u[0].a0[d] = (double)(1.f - x.f[d]), u[0].a1[d] = (double)x.f[d];
         u[0].sy0[d] = y.s0[d], u[0].sy1[d] = y.s1[d];
         u[0].b0[d] = (double)(1.f - y.f[d]), u[0].b1[d] = (double)y.f[d];
+    }
+    // heat_argmax_kernel walks the rows by (segment, phase); make sure the table really has that structure
+    for (int d = 0; d < BOX; d++) {
+        const int g = (d + 4) / 8, ph = (d + 4) % 8;
+        if (u[0].sy0[d] != std::max(g - 1, 0) || u[0].sy1[d] != std::min(g, HM - 1) || u[0].b0[d] != u[0].b0[4 + ph] ||
+            u[0].b1[d] != u[0].b1[4 + ph])
+            return fail(h, VNECT_E_STATE, "internal: x8 upsample table does not have the segment/phase structure");
     }
     HIPCK(h, hipMemcpy(h->d_up, u.data(), sizeof(UpTab), hipMemcpyHostToDevice));
     return VNECT_OK;
@@ -734,17 +740,16 @@ int run_network(vnect_handle* h, bool timed)
 
 int run_pre(vnect_handle* h)
 {
-    HIPCK(h, launch_squarify(h->d_fp, h->sq, h->st));
-    HIPCK(h, launch_pyramid(h->sq, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
+    HIPCK(h, launch_pyramid(h->d_fp, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
                             h->sharded ? h->cfg.pyramid_rank : 0, h->bf16, h->st));
     return VNECT_OK;
 }
 
 int run_post(vnect_handle* h)
 {
-    HIPCK(h, launch_merge(h->sharded ? h->gather : h->tensors[h->t_out].d, h->d_mtabs, h->d_avg, h->S, h->st));
-    HIPCK(h, launch_argmax(h->d_avg, h->d_up, h->d_part, h->st));
-    HIPCK(h, launch_joints(h->d_part, h->d_avg, h->d_fb, h->d_fp, h->cfg.numpy_promotion, h->d_out, h->st));
+    const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
+    HIPCK(h, launch_argmax(maps, h->d_mtabs, h->S, h->d_up, h->d_hm, h->d_part, h->st));
+    HIPCK(h, launch_joints(h->d_part, maps, h->d_mtabs, h->S, h->d_fb, h->d_fp, h->cfg.numpy_promotion, h->d_out, h->st));
     return VNECT_OK;
 }
 
@@ -980,13 +985,12 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     h->slots.resize(h->cfg.num_frame_slots);
     int rc;
     if ((rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
-    if ((rc = dev_alloc(h, &h->sq, (size_t)BOX * BOX * 3))) return rc;
     if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->d_avg, (size_t)4 * HM * HM * NJ))) return rc;
-    if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS * ARG_XBLOCKS))) return rc;
+    if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
+    if ((rc = dev_alloc(h, &h->d_hm, (size_t)NJ * HM * HM))) return rc;
     if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_out, 1))) return rc;
     if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
