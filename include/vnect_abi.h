@@ -140,6 +140,11 @@ typedef struct vnect_layer_info {
     double last_ms;            /* kernel duration in the last profiled frame, device clock (0 if none) */
 } vnect_layer_info;
 int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out);
+/* Raw 100 MHz device-clock stamps of layer idx in the last profiled frame (tuning aid): [0] earliest workgroup start,
+ * [1..8] latest workgroup ends, [9..13] workgroup 0: start, operands requested, first chunk in LDS, K loop done,
+ * stores done; [15] start of the last-dispatched workgroups; [16..18] shader-clock cycles producer wave 0 of workgroup
+ * 0 spent waiting for landings / at the barrier / issuing; [19] cycles consumer wave 0 waited at the barrier. */
+int vnect_get_layer_stamps(vnect_handle* h, int idx, uint64_t* out24);
 
 /* Pyramid sharding over RCCL (one scale per rank; BASELINE.json configs[3]).  A handle created with
  * pyramid_nranks == num_scales runs gen_input_batch and the conv stack for scale `pyramid_rank` only (the S

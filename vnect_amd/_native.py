@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvnect_hip.so")
+LIB_PATH = os.environ.get("VNECT_LIB") or os.path.join(_HERE, "lib", "libvnect_hip.so")  # VNECT_LIB: A/B tuning builds
 _lib = None
 
 MAX_SCALES = 8
@@ -67,6 +67,7 @@ SYMBOLS = {
     "vnect_get_timings": (C.c_int, [_H, C.POINTER(Timings)]),
     "vnect_reset_timings": (C.c_int, [_H]),
     "vnect_get_layer_info": (C.c_int, [_H, C.c_int, C.POINTER(LayerInfo)]),
+    "vnect_get_layer_stamps": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint64)]),
     "vnect_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vnect_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -237,6 +238,12 @@ class Handle:
 
     def reset_timings(self):
         self._ck(lib().vnect_reset_timings(self._h))
+
+    def layer_stamps(self, idx):
+        """Raw device-clock stamps (100 MHz) of layer idx in the last profiled frame; see vnect_get_layer_stamps."""
+        buf = (C.c_uint64 * 24)()
+        self._ck(lib().vnect_get_layer_stamps(self._h, idx, buf))
+        return list(buf)
 
     def layers(self):
         out, i = [], 0

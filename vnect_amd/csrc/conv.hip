@@ -40,6 +40,10 @@ __device__ __forceinline__ void wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// x / d for 0 <= x, x * d < 2^32, with mg = ceil(2^32 / d) (d == 1: mg wraps to 0, handled); one v_mul_hi instead of
+// the ~35-instruction integer division sequence, which sat on every workgroup's critical path before its first load
+__device__ __forceinline__ int fdiv(int x, unsigned mg, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, mg); }
+
 // BF = false: fp32 operands, v_mfma_f32_32x32x2_f32 (exact f32), a 128-B LDS row holds 32 K-elements.
 // BF = true : bf16 operands (activations and weights stored as bf16, fp32 accumulate), v_mfma_f32_32x32x16_bf16,
 //             a 128-B row holds 64 K-elements, so the same ring / swizzle / fragment addressing moves twice the K
@@ -60,12 +64,38 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
     // PRODUCERS (one per SIMD: LDS-DMA issue + landing waits).  An LDS-DMA instruction costs its wave ~100-200
     // issue cycles; in a wave that also owns the MFMA chain that stall idles the matrix pipe, in a partner wave
     // it does not.  All 8 waves meet at one s_barrier per 32-deep chunk.
+    // The ~360-byte argument block spans six scalar-cache lines and the compiler loads its fields where they are first
+    // used: one scalar-cache round trip after another (cold: measured 1.7 us from wave start to the first LDS-DMA;
+    // even as hits ~0.15 us each).  Touch every line now, back to back, then pin the fields the prologue needs in
+    // SGPRs so they are fetched as a few wide loads with a single wait.
+    {
+        typedef __attribute__((address_space(4))) const int kint;
+        kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80], k6 = kp[96];
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6));
+    }
+    struct Hot {
+        const float *in, *w, *bias, *resid, *zeros;
+        unsigned long long* prof;
+        int H, W, Cs, Ho, Wo, M, K, ntaps, cpt, stride, Nvalid, Npad, ldr, ksplit, pixmode, tiles_m, tiles_n;
+        unsigned mg_wo, mg_ho, mg_tn, mg_tm;
+        long long w_phase_stride;
+    } h = {a.in, a.w, a.bias, a.resid, a.zeros, a.prof, a.H, a.W, a.Cs, a.Ho, a.Wo, a.M, a.K, a.ntaps, a.cpt, a.stride, a.Nvalid,
+           a.Npad, a.ldr, a.ksplit, a.pixmode, a.tiles_m, a.tiles_n, a.mg_wo, a.mg_ho, a.mg_tn, a.mg_tm, a.w_phase_stride};
+    asm volatile("" : "+s"(h.in), "+s"(h.w), "+s"(h.bias), "+s"(h.resid), "+s"(h.prof), "+s"(h.zeros), "+s"(h.H), "+s"(h.W),
+                 "+s"(h.Cs), "+s"(h.Ho), "+s"(h.Wo), "+s"(h.M), "+s"(h.K), "+s"(h.ntaps), "+s"(h.cpt), "+s"(h.stride));
+    asm volatile("" : "+s"(h.Nvalid), "+s"(h.Npad), "+s"(h.ldr), "+s"(h.ksplit), "+s"(h.pixmode), "+s"(h.tiles_m), "+s"(h.tiles_n),
+                 "+s"(h.mg_wo), "+s"(h.mg_ho), "+s"(h.mg_tn), "+s"(h.mg_tm), "+s"(h.w_phase_stride));
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const bool producer = threadIdx.x >= 256;
     const int wm = wave >> 1, wn = wave & 1;
     // profiling twin only: the first 8 workgroups (first dispatched) stamp the start, every workgroup its end
     // into one of 8 slots (one address would serialise ~1600 atomics)
-    if (a.prof && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(a.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (h.prof && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(h.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    // phase stamps of workgroup 0 (slots 9-13) and the start of the last-dispatched workgroups (slot 15): tuning aid
+    const bool pstamp = h.prof && threadIdx.x == 0 && blockIdx.x == 0;
+    if (pstamp) h.prof[9] = __builtin_amdgcn_s_memrealtime();
+    if (h.prof && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(h.prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     // XCD-aware tile order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs,
     // so give every XCD a contiguous run of the logical tile sequence (N-tile fastest, then M, then K-slice /
     // phase): tiles that share an activation row block, and all weight tiles, then meet in one XCD's L2.
@@ -77,46 +107,47 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         const int nwg = gridDim.x, id = blockIdx.x;
         const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
         const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
-        tile_n = logical % a.tiles_n;
-        const int t2 = logical / a.tiles_n;
-        tile_m = t2 % a.tiles_m;
-        zz = t2 / a.tiles_m;
+        const int t2 = fdiv(logical, h.mg_tn, h.tiles_n);
+        tile_n = logical - t2 * h.tiles_n;
+        zz = fdiv(t2, h.mg_tm, h.tiles_m);
+        tile_m = t2 - zz * h.tiles_m;
     }
+    if (pstamp) h.prof[20] = __builtin_amdgcn_s_memrealtime();
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int phase = zz / a.ksplit, ks = zz - phase * a.ksplit;
-    const int nch = a.ntaps * a.cpt;
-    const int c0 = (int)(((long long)nch * ks) / a.ksplit);
-    const int c1 = (int)(((long long)nch * (ks + 1)) / a.ksplit);
+    const int phase = zz / h.ksplit, ks = zz - phase * h.ksplit;
+    const int nch = h.ntaps * h.cpt;
+    const int c0 = (int)(((long long)nch * ks) / h.ksplit);
+    const int c1 = (int)(((long long)nch * (ks + 1)) / h.ksplit);
     const int total = c1 - c0;
     const int srow = tid >> 3;
     const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
-    const int pix = a.pixmode;
+    const int pix = h.pixmode;
 
     int a_iy[AR], a_ix[AR], a_pix[AR];
 #pragma unroll
     for (int i = 0; i < AR; i++) {
         int m = m0 + srow + 32 * i;
-        if (m < a.M) {
-            int ox = m % a.Wo, t = m / a.Wo;
-            int oy = t % a.Ho, s = t / a.Ho;
+        if (m < h.M) {
+            const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
+            const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
             // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
-            a_iy[i] = oy * a.stride + (pix && BF ? unit >> 2 : 0);
-            a_ix[i] = ox * a.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
-            a_pix[i] = s * a.H * a.W;
+            a_iy[i] = oy * h.stride + (pix && BF ? unit >> 2 : 0);
+            a_ix[i] = ox * h.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
+            a_pix[i] = s * h.H * h.W;
         } else {
             a_iy[i] = -(1 << 20);
             a_ix[i] = 0;
             a_pix[i] = 0;
         }
     }
-    const T* __restrict__ inp = (const T*)a.in;
-    const T* __restrict__ zero = (const T*)a.zeros;
+    const T* __restrict__ inp = (const T*)h.in;
+    const T* __restrict__ zero = (const T*)h.zeros;
     const T* __restrict__ wp =
-        (const T*)a.w + (long long)phase * a.w_phase_stride + (long long)(n0 + srow) * a.K + unit * EPU + (long long)c0 * EPR;
-    const int* dyp = a.dy + phase * a.ntaps;
-    const int* dxp = a.dx + phase * a.ntaps;
+        (const T*)h.w + (long long)phase * h.w_phase_stride + (long long)(n0 + srow) * h.K + unit * EPU + (long long)c0 * EPR;
+    const int* dyp = a.dy + phase * h.ntaps;
+    const int* dxp = a.dx + phase * h.ntaps;
 
-    int tap = c0 / a.cpt, cc = c0 - tap * a.cpt;
+    int tap = c0 / h.cpt, cc = c0 - tap * h.cpt;
     int a_off[AR];
     bool a_ok[AR];
     auto set_tap = [&](int t) {
@@ -124,8 +155,8 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
 #pragma unroll
         for (int i = 0; i < AR; i++) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            a_ok[i] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            a_off[i] = (a_pix[i] + iy * a.W + ix) * a.Cs + (pix ? 0 : unit * EPU);
+            a_ok[i] = (unsigned)iy < (unsigned)h.H && (unsigned)ix < (unsigned)h.W;
+            a_off[i] = (a_pix[i] + iy * h.W + ix) * h.Cs + (pix ? 0 : unit * EPU);
         }
     };
     auto issue = [&](int stage) {
@@ -136,11 +167,11 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
             GLDS16(src, sb + i * (32 * 32));
         }
 #pragma unroll
-        for (int i = 0; i < BR; i++) GLDS16(wp + (long long)i * 32 * a.K, sb + BM * 32 + i * (32 * 32));
+        for (int i = 0; i < BR; i++) GLDS16(wp + (long long)i * 32 * h.K, sb + BM * 32 + i * (32 * 32));
         wp += EPR;
-        if (++cc == a.cpt) {
+        if (++cc == h.cpt) {
             cc = 0;
-            if (++tap < a.ntaps) set_tap(tap);
+            if (++tap < h.ntaps) set_tap(tap);
         }
     };
     // all but the `young` youngest chunks (NLD instructions each) have landed in LDS
@@ -157,14 +188,20 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         }
     };
 
+    if (pstamp) h.prof[21] = __builtin_amdgcn_s_memrealtime();
     // shortcut tile: loaded now (ordinary loads, ahead of the LDS-DMA queue) so the epilogue never waits for it
-    const bool fused = a.ksplit == 1;
-    const bool has_res = fused && a.resid != nullptr && !producer;
-    const int nlim = fused ? a.Nvalid : a.Npad;
+    const bool fused = h.ksplit == 1;
+    const bool has_res = fused && h.resid != nullptr && !producer;
+    const int nlim = fused ? h.Nvalid : h.Npad;
     const int erow = lane >> 3, ecol = (lane & 7) * 4;
     f32x4 rs[TM][TN][4];
+    f32x4 bpre[TN];  // bias of this wave's columns, requested now for the same reason
+    if (fused && !producer) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) bpre[j] = *(const f32x4*)(h.bias + n0 + wn * WN + j * 32 + ecol);
+    }
     if (has_res) {
-        const float* __restrict__ resid = a.resid;
+        const float* __restrict__ resid = h.resid;
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -174,14 +211,15 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
                     const int m = m0 + wm * WM + i * 32 + erow + 8 * k;
                     const int n = n0 + wn * WN + j * 32 + ecol;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (m < a.M && n < nlim) {  // shortcut layers: os == 1
-                        if constexpr (BF) v = __builtin_convertvector(*(const bf16x4*)((const __bf16*)resid + (long long)m * a.ldr + n), f32x4);
-                        else v = *(const f32x4*)(resid + (long long)m * a.ldr + n);
+                    if (m < h.M && n < nlim) {  // shortcut layers: os == 1
+                        if constexpr (BF) v = __builtin_convertvector(*(const bf16x4*)((const __bf16*)resid + (long long)m * h.ldr + n), f32x4);
+                        else v = *(const f32x4*)(resid + (long long)m * h.ldr + n);
                     }
                     rs[i][j][k] = v;
                 }
     }
 
+    if (pstamp) h.prof[22] = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
@@ -221,6 +259,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         }
     };
 
+    if (pstamp) h.prof[23] = __builtin_amdgcn_s_memrealtime();
     if (producer) {
         // ---- producer waves: keep NS-1 chunks in flight, publish chunk t+1 at barrier t --------------------
         // With MFMAs running, a CU retires only ~one LDS-DMA instruction per 70 cycles (tools/mfma_lds.hip): the
@@ -234,14 +273,22 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         wait_landed(total - 1 < NS - 2 ? total - 1 : NS - 2);
         __builtin_amdgcn_s_barrier();  // chunk 0 visible
         int stage = 0;
+        const bool pacct = h.prof && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
+        long long pw = 0, pb = 0, pi = 0;
         for (int t = 0; t < total; t++) {  // one barrier per chunk, also after the last one (keeps the consumer loop branch-free)
             // chunk t+1 complete in LDS; younger chunks still in flight: t+2 .. min(t+NS-2, total-1)
             const int young = total - 2 - t;
+            const long long q0 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
             wait_landed(young < NS - 3 ? young : NS - 3);
+            const long long q1 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
             __builtin_amdgcn_s_barrier();  // consumers are past chunk t-1: its stage may be refilled
+            const long long q2 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
             if (t + NS - 1 < total) issue(stage == 0 ? NS - 1 : stage - 1);
+            const long long q3 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
+            pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
             stage = stage + 1 == NS ? 0 : stage + 1;
         }
+        if (pacct) h.prof[16] = pw, h.prof[17] = pb, h.prof[18] = pi;
         __builtin_amdgcn_s_barrier();  // matches the consumers' ring-is-dead barrier
         return;
     }
@@ -258,6 +305,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         for (int q = 0; q < 4; q++) rfrag(stg, q, F.a[q], F.b[q]);
     };
     int stage = 0;
+    long long cbw = 0;  // profiling twin: cycles consumer wave 0 waits at the per-chunk barrier
     // One chunk = 16 MFMAs per accumulator.  The reads of chunk t+1 are issued ONE PER MFMA behind the barrier:
     // a wave issues in order, and eight back-to-back ds_read_b128 hold its issue slot for ~35 cycles each when
     // four waves read at once (tools/lds_read.hip) -- behind an MFMA that time is free, in a burst it is not.
@@ -267,6 +315,11 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         mma(cur.a[1], cur.b[1]);
         // after the last chunk the barrier and the reads still run (the reads fetch stale ring data that is never
         // used): no branch sits between the MFMAs
+        if (h.prof) {
+            const long long b0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            cbw += __builtin_amdgcn_s_memtime() - b0;
+        } else
         __builtin_amdgcn_s_barrier();  // chunk t+1 visible; every consumer is past chunk t-1
         if constexpr (TM == 1 && TN == 1 && !BF) {
             const float* Ab = smem + nstage * STAGE + (wm * WM) * 32;
@@ -291,7 +344,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         __builtin_amdgcn_sched_barrier(0);
         stage = nstage;
     };
+    if (pstamp) h.prof[10] = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_barrier();  // chunk 0 visible
+    if (pstamp) h.prof[11] = __builtin_amdgcn_s_memrealtime();
     rall(0, F0);
     for (int t = 0; t < total; t += 2) {
         step(F0, F1, t);
@@ -299,6 +354,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // ring is dead: reuse it as the epilogue scratch
+    if (pstamp) h.prof[12] = __builtin_amdgcn_s_memrealtime(), h.prof[19] = cbw;
 
     // Epilogue.  C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Each 32x32 accumulator goes
     // through a wave-private LDS scratch so that global traffic is 16 B per lane along N (8 lanes = one 128-B line).
@@ -308,9 +364,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
     // Two layers that read the same input run as one GEMM (columns [0, split_n) -> out, the rest -> out2): the whole
     // 64-wide tile lies on one side because split_n is a multiple of the tile width.
     const bool second = fused && a.out2 != nullptr && n0 >= a.split_n;
-    float* __restrict__ outp = !fused ? a.ws + (long long)ks * npix * a.Npad : (second ? a.out2 : a.out);
+    float* __restrict__ outp = !fused ? a.ws + (long long)ks * npix * h.Npad : (second ? a.out2 : a.out);
     const int ncol0 = second ? a.split_n : 0;  // first column of the tensor written by this tile
-    const int ldo = !fused ? a.Npad : (second ? a.ldc2 : a.ldc);
+    const int ldo = !fused ? h.Npad : (second ? a.ldc2 : a.ldc);
     const bool of32 = !BF || !fused || a.out_f32;  // split-K slabs and the final maps stay fp32
     float* scr = smem + wave * (32 * LDT);
 #pragma unroll
@@ -318,7 +374,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
         const int n = n0 + wn * WN + j * 32 + ecol;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, s4 = {1.f, 1.f, 1.f, 1.f}, h4 = {0.f, 0.f, 0.f, 0.f};
         if (fused) {
-            b4 = *(const f32x4*)(a.bias + n);
+            b4 = bpre[j];
             if (a.scale) s4 = *(const f32x4*)(a.scale + n), h4 = *(const f32x4*)(a.shift + n);
         }
         const bool vec = n + 3 < nlim;
@@ -336,8 +392,8 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
                 f32x4 o = *(const f32x4*)&scr[row * LDT + ecol];
                 long long op = m;
                 if (!direct) {
-                    int ox = m % a.Wo, t = m / a.Wo;
-                    int oy = t % a.Ho, s = t / a.Ho;
+                    const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
+                    const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
                     op = ((long long)s * a.OH + oy * a.os + py) * a.OW + ox * a.os + px;
                 }
                 if (fused) {
@@ -348,7 +404,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
                     for (int e = 0; e < 4; e++)
                         if (n + e < a.relu_cols) o[e] = o[e] > 0.f ? o[e] : 0.f;
                 }
-                if (!(m < a.M && n < nlim)) continue;
+                if (!(m < h.M && n < nlim)) continue;
                 if (of32) {
                     float* dst = outp + op * ldo + (n - ncol0);
                     if (vec) {
@@ -372,9 +428,10 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
             }
         }
     }
-    if (a.prof && threadIdx.x == 0) {
+    if (h.prof && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
-        atomicMax(a.prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        if (pstamp) h.prof[13] = __builtin_amdgcn_s_memrealtime();
+        atomicMax(h.prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -413,6 +470,8 @@ template <int BM, int BN, int NS>
 static hipError_t launch_g(ConvArgs a, hipStream_t st)
 {
     a.tiles_m = (a.M + BM - 1) / BM, a.tiles_n = a.Npad / BN;
+    auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    a.mg_wo = magic(a.Wo), a.mg_ho = magic(a.Ho), a.mg_tn = magic(a.tiles_n), a.mg_tm = magic(a.tiles_m);
     dim3 grid(a.tiles_m * a.tiles_n * a.nphase * a.ksplit);
     size_t lds = (size_t)NS * (BM + BN) * 32 * sizeof(float);
     if (a.bf16) hipLaunchKernelGGL((conv_glds_kernel<BM, BN, NS, true>), grid, dim3(512), lds, st, a);
@@ -443,6 +502,8 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
     if (a.Npad % BN != 0 || a.K != a.ntaps * a.cpt * epr || a.nphase * a.ntaps > MAX_TAPS ||
         a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || !a.zeros || (a.bf16 && a.out2 && a.split_n % 64))
         return hipErrorInvalidValue;
+    // range of the multiply-high divisions in the kernel (x / d exact while x * d < 2^32)
+    if ((long long)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1ll << 32) || a.M >= (1 << 24)) return hipErrorInvalidValue;
     if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);  // a 3-stage ring (3 workgroups per CU) was measured: no gain
     if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
     if (BM == 64 && BN == 128) return launch_g<64, 128, 3>(a, st);

@@ -11,7 +11,7 @@ constexpr int NJ = 21;
 constexpr int MAPC = 84;       // 4 maps x 21 joints
 constexpr int MAX_TAPS = 16;
 constexpr int ARG_SLABS = 8;    // arg-max workgroups per joint (6 row segments each)
-constexpr int PROF_SLOTS = 16;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
+constexpr int PROF_SLOTS = 24;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
 //   m = (s*Ho + oy)*Wo + ox, k = (tap, ci), A[m][k] = in[s][oy*stride + dy[tap]][ox*stride + dx[tap]][ci]
@@ -42,6 +42,7 @@ struct ConvArgs {
     int bf16;             // operands and activations are bf16 (accumulators, bias, slabs stay fp32)
     int out_f32;          // bf16 path: this layer writes fp32 (the final maps feed the f64 post-processing)
     int tiles_m, tiles_n; // filled by the launcher
+    unsigned mg_wo, mg_ho, mg_tn, mg_tm;  // ceil(2^32 / d) for d = Wo, Ho, tiles_n, tiles_m (launcher): x / d == umulhi(x, mg) for x*d < 2^32
     long long w_phase_stride;
     int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
 };

@@ -1235,6 +1235,13 @@ int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t
     return VNECT_OK;
 }
 
+int vnect_get_layer_stamps(vnect_handle* h, int idx, uint64_t* out24)
+{
+    if (!h || !out24 || idx < 0 || idx >= (int)h->layers.size()) return h ? fail(h, VNECT_E_ARG, "bad layer index") : VNECT_E_ARG;
+    for (int k = 0; k < PROF_SLOTS; k++) out24[k] = h->h_prof[PROF_SLOTS * idx + k];
+    return VNECT_OK;
+}
+
 int vnect_set_profiling(vnect_handle* h, int on)
 {
     if (!h) return VNECT_E_ARG;
