@@ -34,7 +34,7 @@ for f in range(N):
         r = [(t1 - t0), (t0 - prev_end) if prev_end else 0, st[10] - st[9], st[11] - st[10], st[12] - st[11], st[13] - st[12],
              st[15] - t0, st[9] - t0, st[16] / 23.0, st[17] / 23.0, st[18] / 23.0, st[19] / 23.0]
         if f == N - 1 and os.environ.get('PT_SETUP'):
-            print(l['name'][:24], [round((st[k] - st[9]) / 100.0, 2) for k in (20, 21, 22, 23, 10)])
+            print(l['name'][:24], 'from first chunk landed: K loop of item 0 %.2f, +epilogue issued %.2f, all items %.2f, stores drained %.2f' % tuple((st[k] - st[11]) / 100.0 for k in (20, 21, 12, 13)))
         rows.setdefault(i, []).append(r)
         prev_end = t1
 print("%-30s %5s %3s %5s | %7s %6s | %6s %6s %6s %6s | %6s %6s | %6s %6s %6s %6s" % ("layer", "WGs", "ks", "chunk", "kernel", "gap", "setup", "land", "loop", "epi", "lastwg", "wg0", "p.wait", "p.bar", "p.iss", "c.bar"))

@@ -12,6 +12,7 @@
 // chunks go global -> LDS by LDS-DMA into a ring of stages (details at the kernel).
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace vnect {
@@ -360,11 +361,10 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
     // through a wave-private LDS scratch so that global traffic is 16 B per lane along N (8 lanes = one 128-B line).
     const int py = phase >> 1, px = phase & 1;
     const bool direct = (a.os == 1);
-    const long long npix = (long long)a.S * a.OH * a.OW;
     // Two layers that read the same input run as one GEMM (columns [0, split_n) -> out, the rest -> out2): the whole
     // 64-wide tile lies on one side because split_n is a multiple of the tile width.
     const bool second = fused && a.out2 != nullptr && n0 >= a.split_n;
-    float* __restrict__ outp = !fused ? a.ws + (long long)ks * npix * h.Npad : (second ? a.out2 : a.out);
+    float* __restrict__ outp = !fused ? a.ws + (long long)ks * a.slab_pix * h.Npad : (second ? a.out2 : a.out);
     const int ncol0 = second ? a.split_n : 0;  // first column of the tensor written by this tile
     const int ldo = !fused ? h.Npad : (second ? a.ldc2 : a.ldc);
     const bool of32 = !BF || !fused || a.out_f32;  // split-K slabs and the final maps stay fp32
@@ -435,6 +435,395 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
     }
 }
 
+// Pointers that went through an SGPR pin (inline asm) lose their address space; accesses through them would be FLAT
+// (counted on vmcnt AND lgkmcnt, so the compiler waits for each store before the next: measured 2.5-5 us per epilogue).
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) __bf16 gbf16;
+typedef __attribute__((address_space(1))) const float cgfloat;
+typedef __attribute__((address_space(1))) const __bf16 cgbf16;
+
+// ---------------------------------------------------------------------------------------------------------
+// Streaming variant (64x64 tiles): a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
+// chunks as one stream through the LDS ring.  The producers simply keep issuing -- the first chunks of the next
+// tile land while the consumers are still in the previous tile's epilogue -- so the per-tile fixed cost (wave
+// launch, argument fetch, first-load latency, store drain: ~5 us, more than the K loop of the 1x1 layers) is paid
+// once per workgroup instead of once per tile.  The epilogue works from registers (no LDS scratch: the ring stays
+// live): in the MFMA C layout a lane holds one output column, lanes 0-31 / 32-63 cover two rows of 32 consecutive
+// columns, so every store / shortcut load instruction moves two full 128-byte lines.
+// launch bounds (512, 4): at least 4 waves per SIMD = two workgroups per CU, i.e. a hard 128-VGPR budget
+template <int NS, bool BF>
+__global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
+{
+    using T = typename std::conditional<BF, __bf16, float>::type;
+    constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
+    constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
+    constexpr int BM = 64, BN = 64, STAGE = (BM + BN) * 32, NLD = 4;
+    static_assert(NS >= 3 && NS <= 9, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    {   // argument block: touch every scalar-cache line at once (see conv_glds_kernel)
+        typedef __attribute__((address_space(4))) const int kint;
+        kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80], k6 = kp[96];
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6));
+    }
+    // Fields are pinned in SGPRs in three groups -- common, producer-only, consumer-only (the branch is wave-uniform, so
+    // each path holds only its own) -- and each group is fetched as a few wide scalar loads with ONE wait.  Left to the
+    // compiler, every field is loaded where it is first used: ~0.15 us per field even on scalar-cache hits, 2-4 us
+    // in the epilogue alone (measured).
+    struct Common {
+        int M, Ho, Wo, ntaps, cpt, ksplit, tiles_m, tiles_n, items;
+        unsigned mg_wo, mg_ho, mg_tn, mg_tm, mg_ks;
+    } h = {a.M, a.Ho, a.Wo, a.ntaps, a.cpt, a.ksplit, a.tiles_m, a.tiles_n, a.items, a.mg_wo, a.mg_ho, a.mg_tn, a.mg_tm, a.mg_ks};
+    asm volatile("" : "+s"(h.M), "+s"(h.Ho), "+s"(h.Wo), "+s"(h.ntaps), "+s"(h.cpt), "+s"(h.ksplit), "+s"(h.tiles_m),
+                 "+s"(h.tiles_n), "+s"(h.items), "+s"(h.mg_wo), "+s"(h.mg_ho), "+s"(h.mg_tn), "+s"(h.mg_tm), "+s"(h.mg_ks));
+    unsigned long long* const prof = a.prof;  // not pinned: stays a global-address-space pointer
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    const int wm = wave >> 1, wn = wave & 1;
+    if (prof && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    const bool pstamp = prof && threadIdx.x == 0 && blockIdx.x == 0;
+    if (pstamp) prof[9] = __builtin_amdgcn_s_memrealtime();
+    if (prof && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+
+    // Work items of this workgroup.  XCD-aware order (speed only, never correctness): workgroup ids are dealt
+    // round-robin over the 8 XCDs, so XCD x takes a contiguous eighth of the logical item sequence (N tile fastest,
+    // then M tile, then phase / K slice) -- tiles that share activation rows or weights meet in one L2 -- and its
+    // workgroups walk that range with stride = workgroups per XCD.  Every item is taken exactly once for any grid.
+    int it_first, it_stride, my_n;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, xcd = id & 7, l = id >> 3;
+        const int qd = h.items >> 3, rm = h.items & 7;
+        const int lo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+        const int cnt = qd + (xcd < rm ? 1 : 0);
+        const int nwx = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+        it_first = lo + l, it_stride = nwx;
+        my_n = __builtin_amdgcn_readfirstlane(l < cnt ? (cnt - l + nwx - 1) / nwx : 0);
+    }
+    if (my_n == 0) return;  // whole workgroup: no barrier has been issued yet
+    const int nch = h.ntaps * h.cpt;
+    struct Item {
+        int m0, n0, phase, ks, c0, cnt;
+    };
+    auto decode = [&](int j) __attribute__((always_inline)) {
+        // everything about an item is wave-uniform: say so (the multiply-high runs on the vector ALU), so the item
+        // bookkeeping below compiles to scalar code and scalar branches
+        const int logical = __builtin_amdgcn_readfirstlane(it_first + j * it_stride);
+        const int t2 = __builtin_amdgcn_readfirstlane(fdiv(logical, h.mg_tn, h.tiles_n));
+        const int tile_n = logical - t2 * h.tiles_n;
+        const int zz = __builtin_amdgcn_readfirstlane(fdiv(t2, h.mg_tm, h.tiles_m));
+        const int tile_m = t2 - zz * h.tiles_m;
+        Item it;
+        it.phase = __builtin_amdgcn_readfirstlane(fdiv(zz, h.mg_ks, h.ksplit)), it.ks = zz - it.phase * h.ksplit;
+        it.m0 = tile_m * BM, it.n0 = tile_n * BN;
+        if (h.ksplit == 1) {
+            it.c0 = 0, it.cnt = nch;
+        } else {  // same slice boundaries as conv_glds_kernel
+            it.c0 = (nch * it.ks) / h.ksplit;
+            it.cnt = (nch * (it.ks + 1)) / h.ksplit - it.c0;
+        }
+        return it;
+    };
+    int G = 0;  // chunks in this workgroup's stream
+    if (h.ksplit == 1) G = my_n * nch;
+    else
+        for (int j = 0; j < my_n; j++) G += decode(j).cnt;
+    const int pix = a.pixmode;
+
+    if (producer) {
+        // ---- producer waves: LDS-DMA issue NS-1 chunks ahead of the consumers, across item boundaries -------
+        __builtin_amdgcn_s_setprio(3);
+        struct Prod {
+            const float *in, *w, *zeros;
+            int H, W, Cs, K, stride;
+            unsigned mg_cpt;
+            long long w_phase_stride;
+        } p = {a.in, a.w, a.zeros, a.H, a.W, a.Cs, a.K, a.stride, a.mg_cpt, a.w_phase_stride};
+        asm volatile("" : "+s"(p.in), "+s"(p.w), "+s"(p.zeros), "+s"(p.H), "+s"(p.W), "+s"(p.Cs), "+s"(p.K), "+s"(p.stride),
+                     "+s"(p.mg_cpt), "+s"(p.w_phase_stride));
+        const int srow = tid >> 3;
+        const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
+        const T* __restrict__ inp = (const T*)p.in;
+        const T* __restrict__ zero = (const T*)p.zeros;
+        int a_iy[2], a_ix[2], a_pix[2], a_off[2];
+        bool a_ok[2];
+        const T* wp = nullptr;
+        int tb = 0;  // first tap-table entry of the item's phase (indexing the argument block directly keeps it in constant memory)
+        int tap = 0, cc = 0, rem = 0, jn = 0;
+        auto set_tap = [&](int t) __attribute__((always_inline)) {
+            const int dy = a.dy[tb + t], dx = a.dx[tb + t];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                a_ok[i] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                a_off[i] = (a_pix[i] + iy * p.W + ix) * p.Cs + (pix ? 0 : unit * EPU);
+            }
+        };
+        auto begin_item = [&](int j) __attribute__((always_inline)) {
+            const Item it = decode(j);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int m = it.m0 + srow + 32 * i;
+                if (m < h.M) {
+                    const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
+                    const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
+                    // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
+                    a_iy[i] = oy * p.stride + (pix && BF ? unit >> 2 : 0);
+                    a_ix[i] = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
+                    a_pix[i] = s * p.H * p.W;
+                } else {
+                    a_iy[i] = -(1 << 20), a_ix[i] = 0, a_pix[i] = 0;
+                }
+            }
+            wp = (const T*)p.w + (long long)it.phase * p.w_phase_stride + (long long)(it.n0 + srow) * p.K + unit * EPU + (long long)it.c0 * EPR;
+            tb = it.phase * h.ntaps;
+            tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = it.c0 - tap * h.cpt;
+            rem = it.cnt;
+            set_tap(tap);
+        };
+        auto issue = [&](int stage) __attribute__((always_inline)) {
+            float* sb = smem + stage * STAGE + wave * (8 * 32);  // wave-uniform; the hardware adds lane * 16 B
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const T* src = a_ok[i] ? inp + a_off[i] + cc * EPR : zero;
+                GLDS16(src, sb + i * (32 * 32));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) GLDS16(wp + (long long)i * 32 * p.K, sb + BM * 32 + i * (32 * 32));
+            if (--rem == 0) {
+                if (++jn < my_n) begin_item(jn);
+            } else {
+                wp += EPR;
+                if (++cc == h.cpt) cc = 0, set_tap(++tap);
+            }
+        };
+        auto wait_landed = [&](int young) __attribute__((always_inline)) {  // all but the `young` youngest chunks (NLD instructions each) have landed
+            switch (young) {
+                case 1: wait_vm<NLD>(); break;
+                case 2: wait_vm<2 * NLD>(); break;
+                case 3: wait_vm<3 * NLD>(); break;
+                case 4: wait_vm<4 * NLD>(); break;
+                case 5: wait_vm<5 * NLD>(); break;
+                case 6: wait_vm<6 * NLD>(); break;
+                case 7: wait_vm<7 * NLD>(); break;
+                default: wait_vm<0>(); break;
+            }
+        };
+        begin_item(0);
+#pragma unroll
+        for (int p = 0; p < NS - 1; p++)
+            if (p < G) issue(p);
+        wait_landed(G - 1 < NS - 2 ? G - 1 : NS - 2);
+        __builtin_amdgcn_s_barrier();  // chunk 0 visible
+        int stage = 0;
+        const bool pacct = prof && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
+        long long pw = 0, pb = 0, pi = 0;
+        for (int g = 0; g < G; g++) {  // one barrier per chunk, also after the last one (keeps the consumer loop branch-free)
+            const int young = G - 2 - g;  // chunk g+1 complete in LDS; younger chunks in flight: g+2 .. min(g+NS-2, G-1)
+            const long long q0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            wait_landed(young < NS - 3 ? young : NS - 3);
+            const long long q1 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            __builtin_amdgcn_s_barrier();  // consumers are past chunk g-1: its stage may be refilled
+            const long long q2 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            if (g + NS - 1 < G) issue(stage == 0 ? NS - 1 : stage - 1);
+            const long long q3 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+        if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
+        return;
+    }
+
+    // ---- consumer waves ------------------------------------------------------------------------------------
+    // fragment addresses: row lane&31 of the wave tile, unit (2q + h) ^ ((row >> 1) & 7)
+    int fo[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) fo[q] = (lane & 31) * 32 + (((2 * q + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4);
+    struct Frag {
+        f32x4 a[4], b[4];
+    };
+    Frag F0, F1;
+    f32x16 acc;
+    auto rall = [&](int stg, Frag& F) __attribute__((always_inline)) {
+        const float* Ab = smem + stg * STAGE + (wm * 32) * 32;
+        const float* Bb = smem + stg * STAGE + (BM + wn * 32) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; q++) F.a[q] = *(const f32x4*)(Ab + fo[q]), F.b[q] = *(const f32x4*)(Bb + fo[q]);
+    };
+    auto mma = [&](const f32x4& af, const f32x4& bf) __attribute__((always_inline)) {
+        if constexpr (BF) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+        }
+    };
+    int stage = 0;
+    long long cbw = 0;  // profiling twin: cycles consumer wave 0 waits at the per-chunk barrier
+    // One chunk = 16 MFMAs (fp32).  The 8 fragment reads of chunk g+1 are issued ONE PER MFMA behind the barrier that
+    // publishes it: a wave issues in order, and eight back-to-back ds_read_b128 hold its issue slot for ~35 cycles
+    // each when four waves read at once (tools/lds_read.hip) -- behind an MFMA that time is free.
+    auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
+        const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        mma(cur.a[0], cur.b[0]);
+        mma(cur.a[1], cur.b[1]);
+        if (prof) {
+            const long long b0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            cbw += __builtin_amdgcn_s_memtime() - b0;
+        } else
+            __builtin_amdgcn_s_barrier();  // chunk g+1 visible; every consumer is past chunk g-1
+        if constexpr (!BF) {
+            const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
+            const float* Bb = smem + nstage * STAGE + (BM + wn * 32) * 32;
+#pragma unroll
+            for (int q = 2; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], cur.b[q][e], acc, 0, 0, 0);
+                    const int r = (q - 2) * 4 + e;  // 0..7: fragment r>>1 of A (even r) or B (odd r)
+                    if (r & 1) nxt.b[r >> 1] = *(const f32x4*)(Bb + fo[r >> 1]);
+                    else nxt.a[r >> 1] = *(const f32x4*)(Ab + fo[r >> 1]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one DS read
+                }
+        } else {
+            rall(nstage, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur.a[2], cur.b[2]);
+            mma(cur.a[3], cur.b[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage = nstage;
+    };
+
+    struct Cons {
+        const float *bias, *scale, *shift, *resid;
+        float *out, *out2, *ws;
+        long long slab_pix;
+        int Nvalid, Npad, ldr, ldc, ldc2, split_n, relu_cols, out_f32, os, OH, OW;
+    } c = {a.bias, a.scale, a.shift, a.resid, a.out, a.out2, a.ws, a.slab_pix, a.Nvalid, a.Npad, a.ldr, a.ldc, a.ldc2, a.split_n,
+           a.relu_cols, a.out_f32, a.os, a.OH, a.OW};
+    asm volatile("" : "+s"(c.bias), "+s"(c.scale), "+s"(c.shift), "+s"(c.resid), "+s"(c.out), "+s"(c.out2), "+s"(c.ws), "+s"(c.Nvalid),
+                 "+s"(c.Npad), "+s"(c.ldr), "+s"(c.ldc), "+s"(c.ldc2), "+s"(c.split_n), "+s"(c.relu_cols), "+s"(c.out_f32), "+s"(c.os),
+                 "+s"(c.OH), "+s"(c.OW), "+s"(c.slab_pix));
+    const bool fused = h.ksplit == 1;
+    const bool direct = (c.os == 1);
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);  // C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    cgfloat* resid = fused ? (cgfloat*)c.resid : nullptr;
+    if (pstamp) prof[10] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_barrier();  // chunk 0 visible
+    if (pstamp) prof[11] = __builtin_amdgcn_s_memrealtime();
+    rall(0, F0);
+    for (int j = 0; j < my_n; j++) {
+        const Item it = decode(j);
+        const int n = it.n0 + wn * 32 + col;
+        const int mb = it.m0 + wm * 32 + rhalf;
+        // bias and shortcut of this tile: requested now so the epilogue never waits for them.  (Straight-line code
+        // here and in the epilogue runs once per tile on a cold instruction cache -- ~35 cycles per instruction
+        // measured -- so both are written for instruction count: scalar row bases stepped by additions, one lane offset.)
+        float bias = 0.f, sc = 1.f, sh = 0.f, rs[16];
+        if (fused) {
+            bias = ((cgfloat*)c.bias)[n];
+            if (c.scale) sc = ((cgfloat*)c.scale)[n], sh = ((cgfloat*)c.shift)[n];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) rs[r] = 0.f;
+        if (resid) {
+            // shortcut layers (os == 1).  Row r of the C layout is a UNIFORM distance from the lane's first row, so the
+            // 16 requests share one 32-bit lane offset and differ in a scalar base: no address registers, no branches
+            // (a branch per load would serialise the requests).  Rows past M fall into the tensors' 64-pixel slack
+            // (runtime.cpp), columns past Nvalid re-read column 0; both are masked at the store.
+            const unsigned off = (unsigned)(mb * c.ldr + (n < c.Nvalid ? n : 0));
+            if constexpr (BF) {
+                cgbf16* rp = (cgbf16*)resid;
+#pragma unroll
+                for (int r = 0; r < 16; r++) rs[r] = (float)rp[off], rp += ((r & 3) == 3 ? 5 : 1) * c.ldr;
+            } else {
+                cgfloat* rp = resid;
+#pragma unroll
+                for (int r = 0; r < 16; r++) rs[r] = rp[off], rp += ((r & 3) == 3 ? 5 : 1) * c.ldr;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int t = 0; t < it.cnt; t += 2) {
+            step(F0, F1);
+            if (t + 1 < it.cnt) step(F1, F0);
+        }
+        if (it.cnt & 1) F0 = F1;  // odd chunk count: the fragments of the next item's first chunk sit in F1
+        if (pstamp && j == 0) prof[20] = __builtin_amdgcn_s_memrealtime();  // first item: K loop done
+
+        // epilogue from registers.  One explicit wait for the bias / shortcut values requested before the K loop, with
+        // the values passed through it: otherwise the compiler re-waits (vmcnt(0)) for those loads before every use,
+        // i.e. after every store below, and the 16 stores complete one by one (measured: 2.5-4.8 us per epilogue).
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bias), "+v"(sc), "+v"(sh), "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]),
+                       "+v"(rs[6]), "+v"(rs[7]), "+v"(rs[8]), "+v"(rs[9]), "+v"(rs[10]), "+v"(rs[11]), "+v"(rs[12]), "+v"(rs[13]),
+                       "+v"(rs[14]), "+v"(rs[15]));
+        const int py = it.phase >> 1, px = it.phase & 1;
+        const bool second = fused && c.out2 != nullptr && it.n0 >= c.split_n;  // two layers sharing one input: see conv_glds_kernel
+        gfloat* outp = (gfloat*)(!fused ? c.ws + (long long)it.ks * c.slab_pix * c.Npad : (second ? c.out2 : c.out));
+        const int ncol0 = second ? c.split_n : 0;
+        const int ldo = !fused ? c.Npad : (second ? c.ldc2 : c.ldc);
+        const int nlim = fused ? c.Nvalid : c.Npad;
+        const bool of32 = !BF || !fused || c.out_f32;  // split-K slabs and the final maps stay fp32
+        const bool relu = fused && it.n0 < c.relu_cols;  // uniform per tile: relu_cols is 0, >= N, or a multiple of the tile width
+        if (!fused) bias = 0.f, sc = 1.f, sh = 0.f;       // slabs are raw partial sums
+        if (direct) {
+            // rows past M of the last tile go to the slack of the tensor / slab: no per-row test
+            const unsigned off0 = (unsigned)(mb * ldo + (n - ncol0));
+            auto rows = [&](auto RELU, auto OUTF32) __attribute__((always_inline)) {
+                using OT = typename std::conditional<decltype(OUTF32)::value, gfloat, gbf16>::type;
+                OT* op = (OT*)outp;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float o = acc[r] + bias;
+                    if (c.scale) o = o * sc + sh;
+                    o = o + rs[r];
+                    if constexpr (decltype(RELU)::value) o = __builtin_fmaxf(o, 0.f);
+                    if constexpr (decltype(OUTF32)::value) op[off0] = o;
+                    else op[off0] = (__bf16)o;  // round to nearest even
+                    op += ((r & 3) == 3 ? 5 : 1) * ldo;
+                }
+            };
+            if (n < nlim) {
+                if (of32) {
+                    if (relu) rows(std::true_type{}, std::true_type{});
+                    else rows(std::false_type{}, std::true_type{});
+                } else {
+                    if (relu) rows(std::true_type{}, std::false_type{});
+                    else rows(std::false_type{}, std::false_type{});
+                }
+            }
+        } else {
+            // transposed conv: the 4 phases scatter rows to (2i+py, 2j+px)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
+                const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
+                const int op = (s * c.OH + oy * c.os + py) * c.OW + ox * c.os + px;
+                float o = acc[r] + bias;
+                if (c.scale) o = o * sc + sh;
+                o = o + rs[r];
+                if (relu) o = __builtin_fmaxf(o, 0.f);
+                if (m < h.M && n < nlim) {
+                    const unsigned off = (unsigned)(op * ldo + (n - ncol0));  // tensors are far below 2^32 elements
+                    if (of32) outp[off] = o;
+                    else ((gbf16*)outp)[off] = (__bf16)o;
+                }
+            }
+        }
+        if (pstamp && j == 0) prof[21] = __builtin_amdgcn_s_memrealtime();  // first item: stores issued
+    }
+    if (pstamp) prof[12] = __builtin_amdgcn_s_memrealtime(), prof[19] = cbw;
+    if (prof && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+        if (pstamp) prof[13] = __builtin_amdgcn_s_memrealtime();
+        atomicMax(prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+}
+
 // split-K second pass: slabs summed in slice order (deterministic), then the same epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 {
@@ -447,7 +836,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
         f32x4 part[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)  // all slab loads in flight at once
-            if (k < a.ksplit) part[k] = *(const f32x4*)(a.ws + ((long long)k * a.npix + pix) * a.Npad + n);
+            if (k < a.ksplit) part[k] = *(const f32x4*)(a.ws + ((long long)k * a.slab_pix + pix) * a.Npad + n);
         f32x4 s = part[0];
 #pragma unroll
         for (int k = 1; k < 8; k++)  // summed in slice order: deterministic
@@ -479,6 +868,23 @@ static hipError_t launch_g(ConvArgs a, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int NS>
+static hipError_t launch_stream(ConvArgs a, hipStream_t st)
+{
+    a.tiles_m = (a.M + 63) / 64, a.tiles_n = a.Npad / 64;
+    auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    a.mg_wo = magic(a.Wo), a.mg_ho = magic(a.Ho), a.mg_tn = magic(a.tiles_n), a.mg_tm = magic(a.tiles_m);
+    a.mg_ks = magic(a.ksplit), a.mg_cpt = magic(a.cpt);
+    a.items = a.tiles_m * a.tiles_n * a.nphase * a.ksplit;
+    // two workgroups per CU at most: more tiles than that are walked by the same workgroups (VNECT_MAXWG: tuning)
+    static const int maxwg = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 512;
+    dim3 grid(a.items < maxwg ? a.items : maxwg);
+    size_t lds = (size_t)NS * 128 * 32 * sizeof(float);
+    if (a.bf16) hipLaunchKernelGGL((conv_stream_kernel<NS, true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_stream_kernel<NS, false>), grid, dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
 // Ring depths leave room for two workgroups per CU (<= 80 KiB each): measured faster than one deep ring per CU
 // on every layer of the network (tools/sweep.sh).
 hipError_t conv_setup()
@@ -493,6 +899,17 @@ hipError_t conv_setup()
     if (e != hipSuccess) return e;
     SETG(64, 64, 5) SETG(128, 64, 3) SETG(64, 128, 3)
 #undef SETG
+    e = hipFuncSetAttribute((const void*)conv_stream_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 128 * 32 * 4);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv_stream_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 128 * 32 * 4);
+    if (e != hipSuccess) return e;
+    // two workgroups per CU is what the launch plan assumes: refuse a build that needs more than 128 VGPRs or scratch
+    hipFuncAttributes fa;
+    for (const void* f : {(const void*)conv_stream_kernel<5, false>, (const void*)conv_stream_kernel<5, true>}) {
+        e = hipFuncGetAttributes(&fa, f);
+        if (e != hipSuccess) return e;
+        if (fa.numRegs > 128 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
+    }
     return hipSuccess;
 }
 
@@ -504,6 +921,8 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
         return hipErrorInvalidValue;
     // range of the multiply-high divisions in the kernel (x / d exact while x * d < 2^32)
     if ((long long)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1ll << 32) || a.M >= (1 << 24)) return hipErrorInvalidValue;
+    static const bool stream = !(getenv("VNECT_STREAM") && atoi(getenv("VNECT_STREAM")) == 0);  // A/B against one tile per workgroup
+    if (BM == 64 && BN == 64 && stream) return launch_stream<5>(a, st);
     if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);  // a 3-stage ring (3 workgroups per CU) was measured: no gain
     if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
     if (BM == 64 && BN == 128) return launch_g<64, 128, 3>(a, st);

@@ -24,7 +24,8 @@ struct ConvArgs {
     const float* resid;   // nullptr or same pixel indexing as out
     float* out;
     float* out2;          // second output tensor for columns >= split_n (two layers sharing one input), or nullptr
-    float* ws;            // split-K workspace [ksplit][out pixels][Npad]
+    float* ws;            // split-K workspace [ksplit][slab_pix][Npad]
+    long long slab_pix;   // pixels per slab: out pixels + 64 of slack (the last tile's rows past M land there)
     unsigned long long* prof;  // nullptr, or {min start, 8 x max end} of this launch in 100 MHz s_memrealtime ticks
     const float* zeros;   // >= 128 B of zeros (source of padded taps / rows past M for the LDS-DMA loads)
     int S, H, W, Cs;      // input grid, floats per input pixel
@@ -42,6 +43,8 @@ struct ConvArgs {
     int bf16;             // operands and activations are bf16 (accumulators, bias, slabs stay fp32)
     int out_f32;          // bf16 path: this layer writes fp32 (the final maps feed the f64 post-processing)
     int tiles_m, tiles_n; // filled by the launcher
+    int items;            // work items = tiles_m * tiles_n * nphase * ksplit (launcher; streaming kernel)
+    unsigned mg_ks, mg_cpt;  // same for d = ksplit, cpt
     unsigned mg_wo, mg_ho, mg_tn, mg_tm;  // ceil(2^32 / d) for d = Wo, Ho, tiles_n, tiles_m (launcher): x / d == umulhi(x, mg) for x*d < 2^32
     long long w_phase_stride;
     int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
@@ -49,6 +52,7 @@ struct ConvArgs {
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])
     const float* ws;
+    long long slab_pix;  // pixels per slab (ConvArgs::slab_pix)
     const float* bias;
     const float* scale;
     const float* shift;

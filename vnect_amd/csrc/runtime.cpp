@@ -676,16 +676,19 @@ int finalize_impl(vnect_handle* h)
 #undef NEED
     // buffers
     for (Tensor& t : h->tensors) {
+        // + 64 pixels of slack: the streaming conv kernel's epilogue reads shortcut rows and writes output rows of its
+        // last 64-row tile without a per-row bound check (rows >= M land in the slack and are never read)
+        const size_t slack = (size_t)64 * t.Cs * t.esz;
         char* p = nullptr;
-        int rc = dev_alloc(h, &p, t.bytes());
+        int rc = dev_alloc(h, &p, t.bytes() + slack);
         if (rc) return rc;
         t.d = (float*)p;
-        HIPCK(h, hipMemset(t.d, 0, t.bytes()));
+        HIPCK(h, hipMemset(t.d, 0, t.bytes() + slack));
     }
     size_t ws = 0;
     for (Layer& L : h->layers)
         if (L.op == OP_CONV && L.a.ksplit > 1)
-            ws = std::max(ws, (size_t)L.a.ksplit * L.a.S * L.a.OH * L.a.OW * L.a.Npad);
+            ws = std::max(ws, (size_t)L.a.ksplit * ((size_t)L.a.S * L.a.OH * L.a.OW + 64) * L.a.Npad);
     h->ws_floats = ws;
     if (ws) {
         int rc = dev_alloc(h, &h->ws, ws);
@@ -708,6 +711,7 @@ int finalize_impl(vnect_handle* h)
         if (a.ksplit > 1) {
             ReduceArgs& q = L.r;
             q.ws = h->ws, q.bias = L.bias, q.scale = L.scale, q.shift = L.shift, q.resid = a.resid, q.out = a.out;
+            a.slab_pix = (long long)a.S * a.OH * a.OW + 64, q.slab_pix = a.slab_pix;
             q.npix = (long long)a.S * a.OH * a.OW, q.Npad = a.Npad, q.Nvalid = a.Nvalid, q.ldc = a.ldc, q.ldr = a.ldr;
             q.ksplit = a.ksplit, q.relu_cols = a.relu_cols;
             q.bf16 = a.bf16, q.out_f32 = a.out_f32;
