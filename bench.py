@@ -132,7 +132,7 @@ def main():
     out = None
     tim = None
     if rank == 0 or args.pyramid:  # pyramid: every inference is collective, so every rank must take part
-        # Dominant kernel = vnect::conv_f32_glds_kernel<64,64,5> (the whole conv stack).
+        # Dominant kernel = vnect::conv_stream_kernel<5,BF> (the whole conv stack).
         # Its launch durations are taken live from a profiling twin of the frame graph in which every conv
         # kernel stamps its first-wave start and last-wave end with the 100 MHz device clock (what rocprofv3's
         # kernel trace reports); HIP events on the library's stream bracket the whole replayed frame.
@@ -177,7 +177,7 @@ def main():
                              "algorithmic_bytes_per_frame": BF16_BYTES_PER_FRAME,
                              "mfma_view": {"achieved_tflops": round(achieved, 2), "peak": PEAK_BF16_MFMA,
                                            "frac": round(achieved / PEAK_BF16_MFMA, 4)}}),
-                         kernel="vnect::conv_glds_kernel<64,64,5,%s> (%d launches per frame)"
+                         kernel="vnect::conv_stream_kernel<5,%s> (64x64 tiles, 5-stage LDS ring; %d launches per frame)"
                                 % ("false" if args.precision == "fp32" else "true", tim["conv_launches"]),
                          launches_per_frame=tim["conv_launches"],
                          avg_launch_us=round(conv_ms * 1e3 / tim["conv_launches"], 3),
