@@ -442,6 +442,25 @@ typedef __attribute__((address_space(1))) __bf16 gbf16;
 typedef __attribute__((address_space(1))) const float cgfloat;
 typedef __attribute__((address_space(1))) const __bf16 cgbf16;
 
+// Buffer-addressed LDS-DMA (`buffer_load_dwordx4 v_off, s[srd], s_off offen lds`): address = base + v_off + s_off, 16 bytes per
+// lane to M0-base + lane * 16; a lane whose v_off is >= num_records fetches nothing and lands zeros.  The descriptor
+// type only exists in the device pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void bload_lds(srd_t r, float* lds, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+#else
+typedef int srd_t;
+__device__ __forceinline__ srd_t make_srd(const void*) { return 0; }
+__device__ __forceinline__ void bload_lds(srd_t, float*, unsigned, unsigned) {}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // Streaming variant (64x64 tiles): a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
 // chunks as one stream through the LDS ring.  The producers simply keep issuing -- the first chunks of the next
@@ -451,13 +470,17 @@ typedef __attribute__((address_space(1))) const __bf16 cgbf16;
 // live): in the MFMA C layout a lane holds one output column, lanes 0-31 / 32-63 cover two rows of 32 consecutive
 // columns, so every store / shortcut load instruction moves two full 128-byte lines.
 // launch bounds (512, 4): at least 4 waves per SIMD = two workgroups per CU, i.e. a hard 128-VGPR budget
-template <int NS, bool BF>
+// PROF: 0 = the product kernel (no stamp code at all: a scalar branch between two MFMAs of the dependent chain costs
+// ~35 cycles of matrix-pipe idle, tools/ring_rate.hip); 1 = start / end stamps (bench.py's profiling twin);
+// 2 = per-phase stamps of workgroup 0 as well (tools/phase_table.py, VNECT_PROF_DETAIL=1).
+template <int NS, bool BF, int PROF>
 __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
 {
-    using T = typename std::conditional<BF, __bf16, float>::type;
+    constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
     constexpr int BM = 64, BN = 64, STAGE = (BM + BN) * 32, NLD = 4;
+    constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {   // argument block: touch every scalar-cache line at once (see conv_glds_kernel)
@@ -465,6 +488,7 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
         const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80], k6 = kp[96];
         asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6));
+        static_assert(sizeof(ConvArgs) <= 448 && sizeof(ConvArgs) > 384, "touch every 64-byte line of the argument block");
     }
     // Fields are pinned in SGPRs in three groups -- common, producer-only, consumer-only (the branch is wave-uniform, so
     // each path holds only its own) -- and each group is fetched as a few wide scalar loads with ONE wait.  Left to the
@@ -480,10 +504,10 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
     const int wm = wave >> 1, wn = wave & 1;
-    if (prof && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    const bool pstamp = prof && threadIdx.x == 0 && blockIdx.x == 0;
+    if (P1 && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    const bool pstamp = P2 && threadIdx.x == 0 && blockIdx.x == 0;
     if (pstamp) prof[9] = __builtin_amdgcn_s_memrealtime();
-    if (prof && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (P2 && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
     // Work items of this workgroup.  XCD-aware order (speed only, never correctness): workgroup ids are dealt
     // round-robin over the 8 XCDs, so XCD x takes a contiguous eighth of the logical item sequence (N tile fastest,
@@ -531,68 +555,73 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
 
     if (producer) {
         // ---- producer waves: LDS-DMA issue NS-1 chunks ahead of the consumers, across item boundaries -------
+        // The loop that feeds the ring must not slow the matrix pipe it shares a SIMD with, so it is written for
+        // instruction count: `buffer_load_dwordx4 ... offen lds` takes a 32-bit per-lane offset that is CONSTANT for a
+        // whole tap (the lane's input pixel + 16-byte unit) plus a SCALAR offset (filter tap + channel chunk), i.e. a
+        // chunk costs 4 DMA instructions and a few scalar adds -- no vector address arithmetic, no zero-page select.
+        // Padded taps and rows past M use the buffer bounds check: such a lane's offset is 2^31 (>= num_records), the
+        // hardware fetches nothing and writes zeros.  Negative tap offsets are folded into the descriptor's base
+        // (in - tap_bias), so the scalar offset toff[] is >= 0 (runtime.cpp).
         __builtin_amdgcn_s_setprio(3);
         struct Prod {
-            const float *in, *w, *zeros;
-            int H, W, Cs, K, stride;
+            const float *in, *w;
+            int H, W, Cs, K, stride, tap_bias;
             unsigned mg_cpt;
             long long w_phase_stride;
-        } p = {a.in, a.w, a.zeros, a.H, a.W, a.Cs, a.K, a.stride, a.mg_cpt, a.w_phase_stride};
-        asm volatile("" : "+s"(p.in), "+s"(p.w), "+s"(p.zeros), "+s"(p.H), "+s"(p.W), "+s"(p.Cs), "+s"(p.K), "+s"(p.stride),
+        } p = {a.in, a.w, a.H, a.W, a.Cs, a.K, a.stride, a.tap_bias, a.mg_cpt, a.w_phase_stride};
+        asm volatile("" : "+s"(p.in), "+s"(p.w), "+s"(p.H), "+s"(p.W), "+s"(p.Cs), "+s"(p.K), "+s"(p.stride), "+s"(p.tap_bias),
                      "+s"(p.mg_cpt), "+s"(p.w_phase_stride));
+        const srd_t srdA = make_srd((const char*)p.in - p.tap_bias), srdB = make_srd(p.w);
         const int srow = tid >> 3;
         const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
-        const T* __restrict__ inp = (const T*)p.in;
-        const T* __restrict__ zero = (const T*)p.zeros;
-        int a_iy[2], a_ix[2], a_pix[2], a_off[2];
-        bool a_ok[2];
-        const T* wp = nullptr;
+        constexpr unsigned OOB = 0x80000000u;
+        unsigned a_vo[2], a_mask[2], a_cur[2], b_vo[2];
+        unsigned soA = 0, soB = 0;
         int tb = 0;  // first tap-table entry of the item's phase (indexing the argument block directly keeps it in constant memory)
         int tap = 0, cc = 0, rem = 0, jn = 0;
         auto set_tap = [&](int t) __attribute__((always_inline)) {
-            const int dy = a.dy[tb + t], dx = a.dx[tb + t];
+            soA = (unsigned)__builtin_amdgcn_readfirstlane(a.toff[__builtin_amdgcn_readfirstlane(tb + t)] + cc * 128);
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-                a_ok[i] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                a_off[i] = (a_pix[i] + iy * p.W + ix) * p.Cs + (pix ? 0 : unit * EPU);
-            }
+            for (int i = 0; i < 2; i++) a_cur[i] = a_vo[i] | ((~(a_mask[i] >> t) & 1u) << 31);  // bit 31 set = out of bounds (a select here becomes a divergent branch)
         };
         auto begin_item = [&](int j) __attribute__((always_inline)) {
             const Item it = decode(j);
+            tb = __builtin_amdgcn_readfirstlane(it.phase * h.ntaps);
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int m = it.m0 + srow + 32 * i;
+                a_vo[i] = 0, a_mask[i] = 0;
                 if (m < h.M) {
                     const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
                     const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
                     // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
-                    a_iy[i] = oy * p.stride + (pix && BF ? unit >> 2 : 0);
-                    a_ix[i] = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
-                    a_pix[i] = s * p.H * p.W;
-                } else {
-                    a_iy[i] = -(1 << 20), a_ix[i] = 0, a_pix[i] = 0;
+                    const int iy = oy * p.stride + (pix && BF ? unit >> 2 : 0);
+                    const int ix = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
+                    a_vo[i] = (unsigned)(((s * p.H + iy) * p.W + ix) * p.Cs * ESZ + (pix ? 0 : unit * 16));
+                    for (int t2 = 0; t2 < h.ntaps; t2++) {  // bit t2: tap t2 reads inside the image
+                        const int y = iy + a.dy[tb + t2], x = ix + a.dx[tb + t2];
+                        a_mask[i] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
+                    }
                 }
+                b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
             }
-            wp = (const T*)p.w + (long long)it.phase * p.w_phase_stride + (long long)(it.n0 + srow) * p.K + unit * EPU + (long long)it.c0 * EPR;
-            tb = it.phase * h.ntaps;
-            tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = it.c0 - tap * h.cpt;
-            rem = it.cnt;
+            soB = (unsigned)__builtin_amdgcn_readfirstlane((int)((it.phase * p.w_phase_stride + (long long)it.c0 * EPR) * ESZ));
+            tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = __builtin_amdgcn_readfirstlane(it.c0 - tap * h.cpt);
+            rem = __builtin_amdgcn_readfirstlane(it.cnt);
             set_tap(tap);
         };
         auto issue = [&](int stage) __attribute__((always_inline)) {
             float* sb = smem + stage * STAGE + wave * (8 * 32);  // wave-uniform; the hardware adds lane * 16 B
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const T* src = a_ok[i] ? inp + a_off[i] + cc * EPR : zero;
-                GLDS16(src, sb + i * (32 * 32));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++) GLDS16(wp + (long long)i * 32 * p.K, sb + BM * 32 + i * (32 * 32));
-            if (--rem == 0) {
-                if (++jn < my_n) begin_item(jn);
+            bload_lds(srdA, sb, a_cur[0], soA);
+            bload_lds(srdA, sb + 32 * 32, a_cur[1], soA);
+            bload_lds(srdB, sb + BM * 32, b_vo[0], soB);
+            bload_lds(srdB, sb + BM * 32 + 32 * 32, b_vo[1], soB);
+            rem = __builtin_amdgcn_readfirstlane(rem - 1);
+            if (rem == 0) {
+                jn = __builtin_amdgcn_readfirstlane(jn + 1);
+                if (jn < my_n) begin_item(jn);
             } else {
-                wp += EPR;
+                soA += 128, soB += 128;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
             }
         };
@@ -610,24 +639,31 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         };
         begin_item(0);
 #pragma unroll
-        for (int p = 0; p < NS - 1; p++)
-            if (p < G) issue(p);
+        for (int q = 0; q < NS - 1; q++)
+            if (q < G) issue(q);
         wait_landed(G - 1 < NS - 2 ? G - 1 : NS - 2);
         __builtin_amdgcn_s_barrier();  // chunk 0 visible
-        int stage = 0;
-        const bool pacct = prof && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
+        int stage = 0, g = 0;
+        const bool pacct = P2 && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
         long long pw = 0, pb = 0, pi = 0;
-        for (int g = 0; g < G; g++) {  // one barrier per chunk, also after the last one (keeps the consumer loop branch-free)
-            const int young = G - 2 - g;  // chunk g+1 complete in LDS; younger chunks in flight: g+2 .. min(g+NS-2, G-1)
-            const long long q0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            wait_landed(young < NS - 3 ? young : NS - 3);
-            const long long q1 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        // one barrier per chunk, also after the last one (keeps the consumer loop branch-free).  Steady state: chunk g+1
+        // complete in LDS, chunks g+2 .. g+NS-2 still in flight, chunk g+NS-1 issued behind the barrier that retires
+        // stage g-1.
+        for (; g + NS - 1 < G; g++) {
+            const long long q0 = P2 ? __builtin_amdgcn_s_memtime() : 0;
+            wait_vm<(NS - 3) * NLD>();
+            const long long q1 = P2 ? __builtin_amdgcn_s_memtime() : 0;
             __builtin_amdgcn_s_barrier();  // consumers are past chunk g-1: its stage may be refilled
-            const long long q2 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            if (g + NS - 1 < G) issue(stage == 0 ? NS - 1 : stage - 1);
-            const long long q3 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            const long long q2 = P2 ? __builtin_amdgcn_s_memtime() : 0;
+            issue(stage == 0 ? NS - 1 : stage - 1);
+            const long long q3 = P2 ? __builtin_amdgcn_s_memtime() : 0;
             pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
             stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+        for (; g < G; g++) {  // drain: nothing left to issue
+            const int young = G - 2 - g;
+            wait_landed(young < NS - 3 ? young : NS - 3);
+            __builtin_amdgcn_s_barrier();
         }
         if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
         return;
@@ -666,7 +702,7 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
         mma(cur.a[0], cur.b[0]);
         mma(cur.a[1], cur.b[1]);
-        if (prof) {
+        if constexpr (P2) {
             const long long b0 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
             cbw += __builtin_amdgcn_s_memtime() - b0;
@@ -817,7 +853,7 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         if (pstamp && j == 0) prof[21] = __builtin_amdgcn_s_memrealtime();  // first item: stores issued
     }
     if (pstamp) prof[12] = __builtin_amdgcn_s_memrealtime(), prof[19] = cbw;
-    if (prof && threadIdx.x == 0) {
+    if (P1 && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
         if (pstamp) prof[13] = __builtin_amdgcn_s_memrealtime();
         atomicMax(prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -880,8 +916,20 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     static const int maxwg = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 512;
     dim3 grid(a.items < maxwg ? a.items : maxwg);
     size_t lds = (size_t)NS * 128 * 32 * sizeof(float);
-    if (a.bf16) hipLaunchKernelGGL((conv_stream_kernel<NS, true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv_stream_kernel<NS, false>), grid, dim3(512), lds, st, a);
+    // profiling twin: start / end stamps only, or (VNECT_PROF_DETAIL=1, tools/phase_table.py) the per-phase stamps too
+    static const bool detail = getenv("VNECT_PROF_DETAIL") && atoi(getenv("VNECT_PROF_DETAIL")) != 0;
+    const int prof = a.prof ? (detail ? 2 : 1) : 0;
+#define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<NS, BF, PR>), grid, dim3(512), lds, st, a)
+    if (a.bf16) {
+        if (prof == 0) LAUNCH_STREAM(true, 0);
+        else if (prof == 1) LAUNCH_STREAM(true, 1);
+        else LAUNCH_STREAM(true, 2);
+    } else {
+        if (prof == 0) LAUNCH_STREAM(false, 0);
+        else if (prof == 1) LAUNCH_STREAM(false, 1);
+        else LAUNCH_STREAM(false, 2);
+    }
+#undef LAUNCH_STREAM
     return hipGetLastError();
 }
 
@@ -899,13 +947,13 @@ hipError_t conv_setup()
     if (e != hipSuccess) return e;
     SETG(64, 64, 5) SETG(128, 64, 3) SETG(64, 128, 3)
 #undef SETG
-    e = hipFuncSetAttribute((const void*)conv_stream_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 128 * 32 * 4);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv_stream_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 128 * 32 * 4);
-    if (e != hipSuccess) return e;
     // two workgroups per CU is what the launch plan assumes: refuse a build that needs more than 128 VGPRs or scratch
     hipFuncAttributes fa;
-    for (const void* f : {(const void*)conv_stream_kernel<5, false>, (const void*)conv_stream_kernel<5, true>}) {
+    for (const void* f : {(const void*)conv_stream_kernel<5, false, 0>, (const void*)conv_stream_kernel<5, true, 0>,
+                          (const void*)conv_stream_kernel<5, false, 1>, (const void*)conv_stream_kernel<5, true, 1>,
+                          (const void*)conv_stream_kernel<5, false, 2>, (const void*)conv_stream_kernel<5, true, 2>}) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 128 * 32 * 4);
+        if (e != hipSuccess) return e;
         e = hipFuncGetAttributes(&fa, f);
         if (e != hipSuccess) return e;
         if (fa.numRegs > 128 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;

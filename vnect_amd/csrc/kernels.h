@@ -48,6 +48,10 @@ struct ConvArgs {
     unsigned mg_wo, mg_ho, mg_tn, mg_tm;  // ceil(2^32 / d) for d = Wo, Ho, tiles_n, tiles_m (launcher): x / d == umulhi(x, mg) for x*d < 2^32
     long long w_phase_stride;
     int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
+    // streaming kernel (buffer-addressed LDS-DMA): byte offset of tap [phase*ntaps + tap] from the lane's input pixel,
+    // (dy*W + dx)*Cs*esz + tap_bias with tap_bias = -min over taps (so every entry is >= 0; the descriptor's base is in - tap_bias)
+    int toff[MAX_TAPS];
+    int tap_bias;
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

@@ -708,6 +708,13 @@ int finalize_impl(vnect_handle* h)
         a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
         a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
         a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws, a.zeros = h->zeros;
+        {   // tap byte offsets for the buffer-addressed loads (kernels.h)
+            const int esz = a.bf16 ? 2 : 4, nt = a.nphase * a.ntaps;
+            int lo = 0;
+            for (int t = 0; t < nt; t++) lo = std::min(lo, (a.dy[t] * a.W + a.dx[t]) * a.Cs * esz);
+            a.tap_bias = -lo;
+            for (int t = 0; t < MAX_TAPS; t++) a.toff[t] = t < nt ? (a.dy[t] * a.W + a.dx[t]) * a.Cs * esz + a.tap_bias : 0;
+        }
         if (a.ksplit > 1) {
             ReduceArgs& q = L.r;
             q.ws = h->ws, q.bias = L.bias, q.scale = L.scale, q.shift = L.shift, q.resid = a.resid, q.out = a.out;
