@@ -27,7 +27,7 @@ struct P {
 
 // MODE 0: global_load_lds (64-bit addresses); 1: buffer_load offen lds (voffset + scalar chunk offset); 2: MODE 0 without swizzle
 // LW: loader waves (1, 2, 4); each chunk = 16 wave-instructions of 1 KiB, LW waves issue 16/LW each
-template <int MODE, int LW, int NM, int M16, int RD>
+template <int MODE, int LW, int NM, int M16, int RD, int SCHED>
 __global__ __launch_bounds__(512, 4) void ring(const P p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -175,6 +175,30 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     } while (0)
     auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        if constexpr (SCHED >= 1) {
+            // barrier first, then the 16 MFMAs of this chunk with the 8 reads of the next one behind every second MFMA (SCHED 1)
+            // or behind MFMAs 0-7 (SCHED 2) or 4-11 (SCHED 3)
+            __builtin_amdgcn_s_barrier();
+            const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
+            const float* Bb = smem + nstage * STAGE + (64 + wn * 32) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = q * 4 + e;
+                    MMA(cur.a[q][e], cur.b[q][e], e);
+                    const int r = SCHED == 1 ? (i & 1 ? i >> 1 : -1) : SCHED == 2 ? (i < 8 ? i : -1) : (i >= 4 && i < 12 ? i - 4 : -1);
+                    if (r >= 0) {
+                        if (r & 1) nxt.b[r >> 1] = *(const f32x4*)(Bb + fo[r >> 1]);
+                        else nxt.a[r >> 1] = *(const f32x4*)(Ab + fo[r >> 1]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, SCHED == 1 ? 2 : 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            stage = nstage;
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -210,12 +234,12 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     p.out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
-template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1>
+template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1, int SCHED = 0>
 void run(const char* name, P p, int grid)
 {
-    hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE * 4);
+    hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE * 4);
     for (int rep = 0; rep < 3; rep++) {
-        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD>), dim3(grid), dim3(512), NS * STAGE * 4, 0, p);
+        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED>), dim3(grid), dim3(512), NS * STAGE * 4, 0, p);
         hipDeviceSynchronize();
     }
     std::vector<long long> h(grid * 2);
@@ -246,19 +270,13 @@ int main()
     p.share = 4, p.reads = 1, p.mfma = 16;
     auto cfg = [&](int lfirst, int cons, int lprio, int cprio) { p.lfirst = lfirst, p.cons_waves = cons, p.m16 = 0, p.lprio = lprio, p.cprio = cprio; };
     for (int grid : {256, 512}) {
-        cfg(0, 4, 1, 0); run<1, 4>("base: 4 cons, 4 loaders prio3", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 0>("no MFMA", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 8>("8 MFMA", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0>("16 MFMA no reads", p, grid);
-        cfg(0, 4, 0, 0); run<1, 4>("loaders prio 0", p, grid);
-        cfg(0, 4, 0, 1); run<1, 4>("consumers prio 3", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 16, 1>("16x16x4 MFMAs", p, grid);
-        cfg(0, 4, 0, 1); run<1, 4, 16, 1>("16x16x4 MFMAs, consumers prio 3", p, grid);
-        cfg(0, 2, 1, 0); run<1, 2>("2 cons (w0,1), loaders w4,5 same SIMDs", p, grid);
-        cfg(2, 2, 1, 0); run<1, 2>("2 cons (w0,1), loaders w6,7 other SIMDs", p, grid);
-        cfg(0, 2, 1, 0); run<1, 2, 16, 0, 0>("no reads: 2 cons, loaders same SIMDs", p, grid);
-        cfg(2, 2, 1, 0); run<1, 2, 16, 0, 0>("no reads: 2 cons, loaders other SIMDs", p, grid);
-        cfg(0, 4, 1, 0); run<3, 4>("register staging", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4>("base: barrier mid-chunk, reads behind MFMA 8-15", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1>("barrier first, read every 2nd MFMA", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 2>("barrier first, reads behind MFMA 0-7", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 3>("barrier first, reads behind MFMA 4-11", p, grid);
+        cfg(0, 4, 1, 1); run<1, 4, 16, 0, 1, 1>("barrier first, every 2nd, consumers prio 3", p, grid);
+        cfg(0, 4, 0, 0); run<1, 4, 16, 0, 1, 1>("barrier first, every 2nd, loaders prio 0", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0, 0>("no reads", p, grid);
     }
     return 0;
 }

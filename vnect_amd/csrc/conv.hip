@@ -568,9 +568,13 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
             int H, W, Cs, K, stride, tap_bias;
             unsigned mg_cpt;
             long long w_phase_stride;
-        } p = {a.in, a.w, a.H, a.W, a.Cs, a.K, a.stride, a.tap_bias, a.mg_cpt, a.w_phase_stride};
+            unsigned long long dy_pack, dx_pack;
+        } p = {a.in, a.w, a.H, a.W, a.Cs, a.K, a.stride, a.tap_bias, a.mg_cpt, a.w_phase_stride, a.dy_pack, a.dx_pack};
         asm volatile("" : "+s"(p.in), "+s"(p.w), "+s"(p.H), "+s"(p.W), "+s"(p.Cs), "+s"(p.K), "+s"(p.stride), "+s"(p.tap_bias),
-                     "+s"(p.mg_cpt), "+s"(p.w_phase_stride));
+                     "+s"(p.mg_cpt), "+s"(p.w_phase_stride), "+s"(p.dy_pack), "+s"(p.dx_pack));
+        // tap entry e = phase*ntaps + tap: (dy, dx) from the packed table, byte offset from the lane's input pixel
+        auto tap_dy = [&](int e) __attribute__((always_inline)) { return (int)((p.dy_pack >> (4 * e)) & 15) - 8; };
+        auto tap_dx = [&](int e) __attribute__((always_inline)) { return (int)((p.dx_pack >> (4 * e)) & 15) - 8; };
         const srd_t srdA = make_srd((const char*)p.in - p.tap_bias), srdB = make_srd(p.w);
         const int srow = tid >> 3;
         const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
@@ -580,7 +584,8 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         int tb = 0;  // first tap-table entry of the item's phase (indexing the argument block directly keeps it in constant memory)
         int tap = 0, cc = 0, rem = 0, jn = 0;
         auto set_tap = [&](int t) __attribute__((always_inline)) {
-            soA = (unsigned)__builtin_amdgcn_readfirstlane(a.toff[__builtin_amdgcn_readfirstlane(tb + t)] + cc * 128);
+            const int e = __builtin_amdgcn_readfirstlane(tb + t);
+            soA = (unsigned)__builtin_amdgcn_readfirstlane((tap_dy(e) * p.W + tap_dx(e)) * p.Cs * ESZ + p.tap_bias + cc * 128);
 #pragma unroll
             for (int i = 0; i < 2; i++) a_cur[i] = a_vo[i] | ((~(a_mask[i] >> t) & 1u) << 31);  // bit 31 set = out of bounds (a select here becomes a divergent branch)
         };
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
                     const int ix = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
                     a_vo[i] = (unsigned)(((s * p.H + iy) * p.W + ix) * p.Cs * ESZ + (pix ? 0 : unit * 16));
                     for (int t2 = 0; t2 < h.ntaps; t2++) {  // bit t2: tap t2 reads inside the image
-                        const int y = iy + a.dy[tb + t2], x = ix + a.dx[tb + t2];
+                        const int y = iy + tap_dy(tb + t2), x = ix + tap_dx(tb + t2);
                         a_mask[i] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
                     }
                 }

@@ -48,10 +48,12 @@ struct ConvArgs {
     unsigned mg_wo, mg_ho, mg_tn, mg_tm;  // ceil(2^32 / d) for d = Wo, Ho, tiles_n, tiles_m (launcher): x / d == umulhi(x, mg) for x*d < 2^32
     long long w_phase_stride;
     int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
-    // streaming kernel (buffer-addressed LDS-DMA): byte offset of tap [phase*ntaps + tap] from the lane's input pixel,
-    // (dy*W + dx)*Cs*esz + tap_bias with tap_bias = -min over taps (so every entry is >= 0; the descriptor's base is in - tap_bias)
-    int toff[MAX_TAPS];
+    // streaming kernel (buffer-addressed LDS-DMA): the byte offset of a tap from the lane's input pixel is
+    // (dy*W + dx)*Cs*esz + tap_bias with tap_bias = -min over taps (so it is >= 0; the descriptor's base is in - tap_bias)
     int tap_bias;
+    // the same tap table as 4-bit fields (value + 8, entry [phase*ntaps + tap] at bits 4*entry): the streaming kernel's
+    // producers decode dy / dx with scalar shifts instead of one dependent scalar load per tap
+    unsigned long long dy_pack, dx_pack;
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

@@ -713,7 +713,14 @@ int finalize_impl(vnect_handle* h)
             int lo = 0;
             for (int t = 0; t < nt; t++) lo = std::min(lo, (a.dy[t] * a.W + a.dx[t]) * a.Cs * esz);
             a.tap_bias = -lo;
-            for (int t = 0; t < MAX_TAPS; t++) a.toff[t] = t < nt ? (a.dy[t] * a.W + a.dx[t]) * a.Cs * esz + a.tap_bias : 0;
+            a.dy_pack = a.dx_pack = 0;
+            for (int t = 0; t < nt; t++) {
+                if (a.dy[t] < -8 || a.dy[t] > 7 || a.dx[t] < -8 || a.dx[t] > 7) {
+                    h->err = "internal: filter tap outside the packed range";
+                    return VNECT_E_ARG;
+                }
+                a.dy_pack |= (unsigned long long)(a.dy[t] + 8) << (4 * t), a.dx_pack |= (unsigned long long)(a.dx[t] + 8) << (4 * t);
+            }
         }
         if (a.ksplit > 1) {
             ReduceArgs& q = L.r;
