@@ -700,13 +700,13 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
     };
     int stage = 0;
     long long cbw = 0;  // profiling twin: cycles consumer wave 0 waits at the per-chunk barrier
-    // One chunk = 16 MFMAs (fp32).  The 8 fragment reads of chunk g+1 are issued ONE PER MFMA behind the barrier that
-    // publishes it: a wave issues in order, and eight back-to-back ds_read_b128 hold its issue slot for ~35 cycles
-    // each when four waves read at once (tools/lds_read.hip) -- behind an MFMA that time is free.
+    // One chunk = 16 dependent MFMAs (fp32).  The chunk opens with the barrier that publishes chunk g+1 (and tells the
+    // producers this wave is past chunk g-1: its operands of chunk g are already in registers); the 8 fragment reads of
+    // chunk g+1 then go out behind every second MFMA.  A wave issues in order, so a read that has to queue at the LDS
+    // delays the next MFMA of the chain: spread thin they never do (tools/ring_rate.hip: 92 % of the MFMA bound against
+    // 88 % with the reads packed behind MFMAs 8-15, one workgroup per CU).
     auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
-        mma(cur.a[0], cur.b[0]);
-        mma(cur.a[1], cur.b[1]);
         if constexpr (P2) {
             const long long b0 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
@@ -717,19 +717,23 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
             const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
             const float* Bb = smem + nstage * STAGE + (BM + wn * 32) * 32;
 #pragma unroll
-            for (int q = 2; q < 4; q++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], cur.b[q][e], acc, 0, 0, 0);
-                    const int r = (q - 2) * 4 + e;  // 0..7: fragment r>>1 of A (even r) or B (odd r)
-                    if (r & 1) nxt.b[r >> 1] = *(const f32x4*)(Bb + fo[r >> 1]);
-                    else nxt.a[r >> 1] = *(const f32x4*)(Ab + fo[r >> 1]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one DS read
+                    if (e & 1) {
+                        const int r = q * 2 + (e >> 1);  // 0..7: fragment r>>1 of A (even r) or B (odd r)
+                        if (r & 1) nxt.b[r >> 1] = *(const f32x4*)(Bb + fo[r >> 1]);
+                        else nxt.a[r >> 1] = *(const f32x4*)(Ab + fo[r >> 1]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // two MFMAs ...
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one DS read
+                    }
                 }
         } else {
             rall(nstage, nxt);
             __builtin_amdgcn_sched_barrier(0);
+            mma(cur.a[0], cur.b[0]);
+            mma(cur.a[1], cur.b[1]);
             mma(cur.a[2], cur.b[2]);
             mma(cur.a[3], cur.b[3]);
         }
