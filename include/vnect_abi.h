@@ -56,6 +56,10 @@ typedef struct vnect_config {
     int32_t pyramid_nranks;           /* 0/1 = off; else must equal num_scales: this handle runs the
                                          pre-processing and conv stack of ONE scale (see vnect_comm_init) */
     int32_t pyramid_rank;             /* which scale (0 .. pyramid_nranks-1)                       */
+    int32_t keep_activations;         /* 0 (default) = layer outputs share an activation arena sized for the peak
+                                         live set, so weights + activations stay in the Infinity Cache between
+                                         frames; 1 = one private buffer per layer output, which is what
+                                         vnect_read_activation needs to return an inner layer (tests, debugging) */
 } vnect_config;
 
 /* Replaces VNectEstimator.__init__ (src/estimator.py:27-68): session + graph + 42 + 63 filters. */

@@ -51,13 +51,21 @@ def _log(name, obj):
 
 
 # ------------------------------------------------------------------------------------------ conv stack
-def test_conv_stack_every_layer(h3, oracle_net):
-    """a1-a7: every named activation of the HIP graph vs the oracle, S=3 at BASELINE scales."""
+def test_conv_stack_every_layer(h3, weights, oracle_net):
+    """a1-a7: every named activation of the HIP graph vs the oracle, S=3 at BASELINE scales.  Inner layers are read from
+    a handle with private buffers (keep_activations); the product default shares an arena between layers, must refuse to
+    return an inner layer, and must produce bit-identical maps."""
     import oracle
     from tests import helpers
     batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
     ref = oracle_net.forward(batch)
+    arena_out = h3.forward(batch)
+    with pytest.raises(_native().VnectError):
+        h3.activation("res3a")
+    assert np.array_equal(h3.activation("res5c_branch2c"), arena_out)  # the final maps stay readable
+    h3 = _handle(BASELINE_SCALES, weights, keep_activations=True)
     out = h3.forward(batch)
+    assert np.array_equal(out, arena_out)
     rows, bad = [], []
     names = [L["name"] for L in h3.layers()]
     acts = ["conv1", "pool1"]
@@ -85,6 +93,7 @@ def test_conv_stack_every_layer(h3, oracle_net):
     _log("layer_errors.json", rows)
     for r in rows:
         print("%-24s %-20s rel err %.3g" % (r[0], r[1], r[2]))
+    h3.close()
     assert not bad, "first mismatching layers: %r" % bad[:3]
     assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4
 
@@ -369,7 +378,7 @@ def test_bf16_path_gated_against_fp32(weights, oracle_net, h3):
     from tests import helpers
     batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
     ref = oracle_net.forward(batch)
-    hb = _handle(BASELINE_SCALES, weights, precision=_native().BF16)
+    hb = _handle(BASELINE_SCALES, weights, precision=_native().BF16, keep_activations=True)
     out = hb.forward(batch)
     f32 = h3.forward(batch)
     rows = []

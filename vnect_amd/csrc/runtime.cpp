@@ -71,6 +71,8 @@ struct vnect_handle {
     size_t ws_floats = 0;
     float* zeros = nullptr;
     std::vector<void*> dev_allocs;
+    bool keep_activations = true;  // one private buffer per layer output (vnect_read_activation needs it); false = arena
+    size_t arena_bytes = 0;
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; };
@@ -675,15 +677,62 @@ int finalize_impl(vnect_handle* h)
     }
 #undef NEED
     // buffers
-    for (Tensor& t : h->tensors) {
-        // + 64 pixels of slack: the streaming conv kernel's epilogue reads shortcut rows and writes output rows of its
-        // last 64-row tile without a per-row bound check (rows >= M land in the slack and are never read)
-        const size_t slack = (size_t)64 * t.Cs * t.esz;
-        char* p = nullptr;
-        int rc = dev_alloc(h, &p, t.bytes() + slack);
+    // + 64 pixels of slack per tensor: the streaming conv kernel's epilogue reads shortcut rows and writes output rows of
+    // its last 64-row tile without a per-row bound check (rows >= M land in the slack and are never read)
+    auto padded = [](const Tensor& t) { return (t.bytes() + (size_t)64 * t.Cs * t.esz + 255) & ~(size_t)255; };
+    if (!h->keep_activations) {
+        // Activation arena: a tensor lives from the layer that writes it to the last layer that reads it, and tensors with
+        // disjoint lifetimes share addresses (first fit over the live intervals).  The per-frame working set is then the
+        // peak live set (~0.1 GB at S = 3) instead of one buffer per layer output (~0.35 GB), so weights + activations stay
+        // inside the 256 MiB Infinity Cache from frame to frame.
+        const int nt = (int)h->tensors.size(), nl = (int)h->layers.size();
+        std::vector<int> first(nt, nl + 1), last(nt, -2);
+        auto touch = [&](int t, int l) {
+            if (t < 0) return;
+            first[t] = std::min(first[t], l), last[t] = std::max(last[t], l);
+        };
+        touch(h->t_input4, -1);  // written by the pre-processing
+        for (int l = 0; l < nl; l++) {
+            const Layer& L = h->layers[l];
+            touch(L.in, l), touch(L.resid, l), touch(L.out, l), touch(L.out2, l);
+        }
+        touch(h->t_out, nl);  // read by the post-processing
+        std::vector<int> order(nt);
+        for (int i = 0; i < nt; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return first[x] != first[y] ? first[x] < first[y] : x < y; });
+        std::vector<size_t> off(nt, 0);
+        std::vector<int> placed;
+        size_t total = 0;
+        for (int t : order) {
+            if (last[t] < first[t]) first[t] = -1, last[t] = nl;  // never touched by a layer: keep it private
+            const size_t need = padded(h->tensors[t]);
+            // candidate offsets: 0 and the end of every placed tensor whose lifetime overlaps; take the lowest that fits
+            std::vector<std::pair<size_t, size_t>> busy;  // [begin, end) of overlapping placed tensors
+            for (int q : placed)
+                if (!(last[q] < first[t] || last[t] < first[q])) busy.push_back({off[q], off[q] + padded(h->tensors[q])});
+            std::sort(busy.begin(), busy.end());
+            size_t pos = 0;
+            for (auto& b : busy) {
+                if (pos + need <= b.first) break;
+                pos = std::max(pos, b.second);
+            }
+            off[t] = pos, total = std::max(total, pos + need);
+            placed.push_back(t);
+        }
+        char* base = nullptr;
+        int rc = dev_alloc(h, &base, total);
         if (rc) return rc;
-        t.d = (float*)p;
-        HIPCK(h, hipMemset(t.d, 0, t.bytes() + slack));
+        HIPCK(h, hipMemset(base, 0, total));
+        for (int t = 0; t < nt; t++) h->tensors[t].d = (float*)(base + off[t]);
+        h->arena_bytes = total;
+    } else {
+        for (Tensor& t : h->tensors) {
+            char* p = nullptr;
+            int rc = dev_alloc(h, &p, padded(t));
+            if (rc) return rc;
+            t.d = (float*)p;
+            HIPCK(h, hipMemset(t.d, 0, padded(t)));
+        }
     }
     size_t ws = 0;
     for (Layer& L : h->layers)
@@ -994,6 +1043,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     h->Snet = sharded ? 1 : cfg->num_scales;
     h->bf16 = cfg->precision == VNECT_BF16;
     h->sharded = sharded;
+    h->keep_activations = cfg->keep_activations != 0;
     if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
     if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
     *out = h;  // returned even on failure below so the caller can read the message, then destroy
@@ -1238,6 +1288,8 @@ int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t
     const Tensor& t = h->tensors[it->second];
     shape4[0] = t.S, shape4[1] = t.H, shape4[2] = t.W, shape4[3] = t.C;
     if (!out) return VNECT_OK;
+    if (!h->keep_activations && it->second != h->t_out)
+        return fail(h, VNECT_E_STATE, "vnect_read_activation: inner layers share an arena; create the handle with keep_activations = 1");
     const size_t npix = (size_t)t.S * t.H * t.W;
     if ((int64_t)(npix * t.C) > capacity) return fail(h, VNECT_E_ARG, "vnect_read_activation: capacity too small");
     HIPCK(h, hipSetDevice(h->cfg.device));
