@@ -12,7 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLDS16(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 typedef __attribute__((address_space(3))) void* ldsp;
 
-constexpr int NS = 5, STAGE = 128 * 32;  // floats per stage
+constexpr int NS = 5;
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -27,14 +27,15 @@ struct P {
 
 // MODE 0: global_load_lds (64-bit addresses); 1: buffer_load offen lds (voffset + scalar chunk offset); 2: MODE 0 without swizzle
 // LW: loader waves (1, 2, 4); each chunk = 16 wave-instructions of 1 KiB, LW waves issue 16/LW each
-template <int MODE, int LW, int NM, int M16, int RD, int SCHED>
+template <int MODE, int LW, int NM, int M16, int RD, int SCHED, int PCS>
 __global__ __launch_bounds__(512, 4) void ring(const P p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
     const int G = p.chunks;
-    constexpr int PER = 16 / LW;  // DMA instructions per loader wave per chunk
+    constexpr int PER = PCS / LW;  // DMA instructions per loader wave per chunk
+    constexpr int STAGE = PCS * 256;  // floats per stage
     long long t0 = 0, r0 = 0;
     if (producer) {
         const int lw = wave - p.lfirst;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         for (int i = 0; i < PER; i++) {
             const int piece = lw + i * LW, row = piece * 8 + srow;
             const int unit = MODE == 2 ? (lane & 7) : ((lane & 7) ^ ((row >> 1) & 7));
-            const float* base = row < 64 ? aw + (size_t)row * p.kwin * 32 : p.b + (size_t)(row - 64) * p.kwin * 32;
+            const float* base = row < 64 ? aw + (size_t)row * p.kwin * 32 : p.b + (size_t)((row - 64) & 63) * p.kwin * 32 + (row >= 128 ? 16 * p.kwin * 32 : 0);
             src[i] = base + unit * 4;
             voff[i] = (unsigned)((const char*)src[i] - (const char*)p.a);
         }
@@ -234,12 +235,12 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     p.out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
-template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1, int SCHED = 0>
+template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1, int SCHED = 0, int PCS = 16>
 void run(const char* name, P p, int grid)
 {
-    hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE * 4);
+    hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD, SCHED, PCS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * PCS * 1024);
     for (int rep = 0; rep < 3; rep++) {
-        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED>), dim3(grid), dim3(512), NS * STAGE * 4, 0, p);
+        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED, PCS>), dim3(grid), dim3(512), NS * PCS * 1024, 0, p);
         hipDeviceSynchronize();
     }
     std::vector<long long> h(grid * 2);
@@ -248,7 +249,7 @@ void run(const char* name, P p, int grid)
     for (int i = 0; i < grid; i++) cy.push_back((double)h[2 * i]), rt.push_back((double)h[2 * i + 1]);
     std::sort(cy.begin(), cy.end()), std::sort(rt.begin(), rt.end());
     const double c = cy[grid / 2], t = rt[grid / 2] * 10e-9;  // 100 MHz ticks
-    const double bytes = (double)p.chunks * 16384, wgpc = grid / 256.0;
+    const double bytes = (double)p.chunks * PCS * 1024, wgpc = grid / 256.0;
     printf("%-34s grid %4d lw %d mfma %d reads %d share %d | %7.0f cyc/chunk/WG  %5.1f B/clk/CU  %5.1f GB/s/CU  clk %.2f GHz  mfma-bound %4.0f%%\n", name,
            grid, LW, NM, RD, p.share, c / p.chunks, bytes / c * wgpc, bytes / t * wgpc / 1e9, c / t / 1e9, 64.0 * (NM ? NM : 16) * wgpc / (c / p.chunks) * 100);
 }
@@ -269,14 +270,11 @@ int main()
     p.a = a, p.b = b, p.out = out, p.res = res, p.chunks = 510, p.kwin = kwin;
     p.share = 4, p.reads = 1, p.mfma = 16;
     auto cfg = [&](int lfirst, int cons, int lprio, int cprio) { p.lfirst = lfirst, p.cons_waves = cons, p.m16 = 0, p.lprio = lprio, p.cprio = cprio; };
-    for (int grid : {256, 512}) {
-        cfg(0, 4, 1, 0); run<1, 4>("base: barrier mid-chunk, reads behind MFMA 8-15", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1>("barrier first, read every 2nd MFMA", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 2>("barrier first, reads behind MFMA 0-7", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 3>("barrier first, reads behind MFMA 4-11", p, grid);
-        cfg(0, 4, 1, 1); run<1, 4, 16, 0, 1, 1>("barrier first, every 2nd, consumers prio 3", p, grid);
-        cfg(0, 4, 0, 0); run<1, 4, 16, 0, 1, 1>("barrier first, every 2nd, loaders prio 0", p, grid);
-        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0, 0>("no reads", p, grid);
+    for (int grid : {200, 256}) {
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1>("16 KiB stages (64x64 tile)", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24>("24 KiB stages (64x32 tile x 2 K groups)", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 0, 0, 1, 1, 24>("24 KiB stages, no MFMA", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 32>("32 KiB stages (32x32 x 4 K groups / 64x64 x 2)", p, grid);
     }
     return 0;
 }

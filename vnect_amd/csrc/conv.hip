@@ -473,14 +473,24 @@ __device__ __forceinline__ void bload_lds(srd_t, float*, unsigned, unsigned) {}
 // PROF: 0 = the product kernel (no stamp code at all: a scalar branch between two MFMAs of the dependent chain costs
 // ~35 cycles of matrix-pipe idle, tools/ring_rate.hip); 1 = start / end stamps (bench.py's profiling twin);
 // 2 = per-phase stamps of workgroup 0 as well (tools/phase_table.py, VNECT_PROF_DETAIL=1).
-template <int NS, bool BF, int PROF>
-__global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
+//
+// Tile shapes: the four consumer waves own one 32x32 accumulator each, arranged as (BM/32) x (BN/32) x KG.  KG > 1 is
+// the IN-WORKGROUP K split for layers whose 64x64 tiles cannot fill the chip (M = 1587 at 23x23): K group kg takes the
+// kg-th 128-byte run of every KG*128-byte step, and the groups' accumulators are summed through LDS in group order before
+// the epilogue -- deterministic, no partial slabs in HBM, no second launch.  A step then moves KG*(BM+BN)*128 bytes:
+// 24 KiB for 64x32x2, 32 KiB for 32x32x4, which the LDS-DMA sustains at one workgroup per CU (tools/ring_rate.hip).
+template <int BM, int BN, int KG, int NS, bool BF, int PROF>
+__global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
-    constexpr int BM = 64, BN = 64, STAGE = (BM + BN) * 32, NLD = 4;
+    constexpr int ARB = BM / 32, BRB = BN / 32, WMN = ARB * BRB;  // 32-row blocks of A and B; accumulators per K group
+    constexpr int ROWS = BM + BN, SUB = ROWS * 32;               // one K group's image: ROWS x 128 B
+    constexpr int STAGE = SUB * KG, NLD = KG * ROWS / 32;        // floats per ring stage; LDS-DMA instructions per producer wave per step
+    constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x 4 KiB, then WMN*(KG-1) flags
     constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
+    static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {   // argument block: touch every scalar-cache line at once (see conv_glds_kernel)
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
     unsigned long long* const prof = a.prof;  // not pinned: stays a global-address-space pointer
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kg = wave / WMN, wr = wave % WMN, wm = wr / BRB, wn = wr % BRB;  // consumers: K group, tile row / column block
     if (P1 && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     const bool pstamp = P2 && threadIdx.x == 0 && blockIdx.x == 0;
     if (pstamp) prof[9] = __builtin_amdgcn_s_memrealtime();
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         my_n = __builtin_amdgcn_readfirstlane(l < cnt ? (cnt - l + nwx - 1) / nwx : 0);
     }
     if (my_n == 0) return;  // whole workgroup: no barrier has been issued yet
-    const int nch = h.ntaps * h.cpt;
+    const int nch = h.ntaps * h.cpt;  // K steps per tile (the launcher passes cpt in steps of KG chunks)
     struct Item {
         int m0, n0, phase, ks, c0, cnt;
     };
@@ -579,21 +589,21 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         const int srow = tid >> 3;
         const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
         constexpr unsigned OOB = 0x80000000u;
-        unsigned a_vo[2], a_mask[2], a_cur[2], b_vo[2];
+        unsigned a_vo[ARB], a_mask[ARB], a_cur[ARB], b_vo[BRB];
         unsigned soA = 0, soB = 0;
         int tb = 0;  // first tap-table entry of the item's phase (indexing the argument block directly keeps it in constant memory)
         int tap = 0, cc = 0, rem = 0, jn = 0;
         auto set_tap = [&](int t) __attribute__((always_inline)) {
             const int e = __builtin_amdgcn_readfirstlane(tb + t);
-            soA = (unsigned)__builtin_amdgcn_readfirstlane((tap_dy(e) * p.W + tap_dx(e)) * p.Cs * ESZ + p.tap_bias + cc * 128);
+            soA = (unsigned)__builtin_amdgcn_readfirstlane((tap_dy(e) * p.W + tap_dx(e)) * p.Cs * ESZ + p.tap_bias + cc * (128 * KG));
 #pragma unroll
-            for (int i = 0; i < 2; i++) a_cur[i] = a_vo[i] | ((~(a_mask[i] >> t) & 1u) << 31);  // bit 31 set = out of bounds (a select here becomes a divergent branch)
+            for (int i = 0; i < ARB; i++) a_cur[i] = a_vo[i] | ((~(a_mask[i] >> t) & 1u) << 31);  // bit 31 set = out of bounds (a select here becomes a divergent branch)
         };
         auto begin_item = [&](int j) __attribute__((always_inline)) {
             const Item it = decode(j);
             tb = __builtin_amdgcn_readfirstlane(it.phase * h.ntaps);
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < ARB; i++) {
                 const int m = it.m0 + srow + 32 * i;
                 a_vo[i] = 0, a_mask[i] = 0;
                 if (m < h.M) {
@@ -608,25 +618,29 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
                         a_mask[i] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
                     }
                 }
-                b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
             }
-            soB = (unsigned)__builtin_amdgcn_readfirstlane((int)((it.phase * p.w_phase_stride + (long long)it.c0 * EPR) * ESZ));
+#pragma unroll
+            for (int i = 0; i < BRB; i++) b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
+            soB = (unsigned)__builtin_amdgcn_readfirstlane((int)((it.phase * p.w_phase_stride + (long long)it.c0 * (EPR * KG)) * ESZ));
             tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = __builtin_amdgcn_readfirstlane(it.c0 - tap * h.cpt);
             rem = __builtin_amdgcn_readfirstlane(it.cnt);
             set_tap(tap);
         };
         auto issue = [&](int stage) __attribute__((always_inline)) {
             float* sb = smem + stage * STAGE + wave * (8 * 32);  // wave-uniform; the hardware adds lane * 16 B
-            bload_lds(srdA, sb, a_cur[0], soA);
-            bload_lds(srdA, sb + 32 * 32, a_cur[1], soA);
-            bload_lds(srdB, sb + BM * 32, b_vo[0], soB);
-            bload_lds(srdB, sb + BM * 32 + 32 * 32, b_vo[1], soB);
+#pragma unroll
+            for (int k = 0; k < KG; k++) {  // K group k: the k-th 128-byte run of the step, landed in its own image
+#pragma unroll
+                for (int i = 0; i < ARB; i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], soA + k * 128);
+#pragma unroll
+                for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], soB + k * 128);
+            }
             rem = __builtin_amdgcn_readfirstlane(rem - 1);
             if (rem == 0) {
                 jn = __builtin_amdgcn_readfirstlane(jn + 1);
                 if (jn < my_n) begin_item(jn);
             } else {
-                soA += 128, soB += 128;
+                soA += 128 * KG, soB += 128 * KG;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
             }
         };
@@ -685,8 +699,8 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
     Frag F0, F1;
     f32x16 acc;
     auto rall = [&](int stg, Frag& F) __attribute__((always_inline)) {
-        const float* Ab = smem + stg * STAGE + (wm * 32) * 32;
-        const float* Bb = smem + stg * STAGE + (BM + wn * 32) * 32;
+        const float* Ab = smem + stg * STAGE + kg * SUB + (wm * 32) * 32;
+        const float* Bb = smem + stg * STAGE + kg * SUB + (BM + wn * 32) * 32;
 #pragma unroll
         for (int q = 0; q < 4; q++) F.a[q] = *(const f32x4*)(Ab + fo[q]), F.b[q] = *(const f32x4*)(Bb + fo[q]);
     };
@@ -714,8 +728,8 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         } else
             __builtin_amdgcn_s_barrier();  // chunk g+1 visible; every consumer is past chunk g-1
         if constexpr (!BF) {
-            const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
-            const float* Bb = smem + nstage * STAGE + (BM + wn * 32) * 32;
+            const float* Ab = smem + nstage * STAGE + kg * SUB + (wm * 32) * 32;
+            const float* Bb = smem + nstage * STAGE + kg * SUB + (BM + wn * 32) * 32;
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -756,6 +770,10 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
     const int col = lane & 31, rhalf = 4 * (lane >> 5);  // C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     cgfloat* resid = fused ? (cgfloat*)c.resid : nullptr;
     if (pstamp) prof[10] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (KG > 1) {
+        if (threadIdx.x < (KG - 1) * WMN) ((volatile int*)(smem + SCRATCH + (KG - 1) * WMN * 1024))[threadIdx.x] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // chunk 0 visible
     if (pstamp) prof[11] = __builtin_amdgcn_s_memrealtime();
     rall(0, F0);
@@ -767,13 +785,13 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         // here and in the epilogue runs once per tile on a cold instruction cache -- ~35 cycles per instruction
         // measured -- so both are written for instruction count: scalar row bases stepped by additions, one lane offset.)
         float bias = 0.f, sc = 1.f, sh = 0.f, rs[16];
-        if (fused) {
+        if (fused && kg == 0) {
             bias = ((cgfloat*)c.bias)[n];
             if (c.scale) sc = ((cgfloat*)c.scale)[n], sh = ((cgfloat*)c.shift)[n];
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) rs[r] = 0.f;
-        if (resid) {
+        if (resid && kg == 0) {
             // shortcut layers (os == 1).  Row r of the C layout is a UNIFORM distance from the lane's first row, so the
             // 16 requests share one 32-bit lane offset and differ in a scalar base: no address registers, no branches
             // (a branch per load would serialise the requests).  Rows past M fall into the tensors' 64-pixel slack
@@ -797,6 +815,32 @@ __global__ __launch_bounds__(512, 4) void conv_stream_kernel(const ConvArgs a)
         }
         if (it.cnt & 1) F0 = F1;  // odd chunk count: the fragments of the next item's first chunk sit in F1
         if (pstamp && j == 0) prof[20] = __builtin_amdgcn_s_memrealtime();  // first item: K loop done
+        if constexpr (KG > 1) {
+            // K groups 1.. hand their accumulators to group 0 through LDS (lane-linear 16-byte slots: conflict-free) and go
+            // on to the next item; group 0 adds them in group order.  The flag carries the item number, so nothing is
+            // reset; a partial is not overwritten early because the writer first has to pass the next item's K-loop
+            // barriers, which group 0 joins only after this epilogue.
+            float* part = smem + SCRATCH;
+            volatile int* flags = (volatile int*)(smem + SCRATCH + (KG - 1) * WMN * 1024);
+            if (kg > 0) {
+                float* dst = part + ((kg - 1) * WMN + wr) * 1024 + lane * 4;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) *(f32x4*)(dst + r4 * 256) = f32x4{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) flags[(kg - 1) * WMN + wr] = j + 1;
+                continue;
+            }
+#pragma unroll
+            for (int k = 1; k < KG; k++) {
+                while (flags[(k - 1) * WMN + wr] != j + 1) __builtin_amdgcn_s_sleep(1);
+                const float* src = part + ((k - 1) * WMN + wr) * 1024 + lane * 4;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const f32x4 v = *(const f32x4*)(src + r4 * 256);
+                    acc[4 * r4] += v[0], acc[4 * r4 + 1] += v[1], acc[4 * r4 + 2] += v[2], acc[4 * r4 + 3] += v[3];
+                }
+            }
+        }
 
         // epilogue from registers.  One explicit wait for the bias / shortcut values requested before the K loop, with
         // the values passed through it: otherwise the compiler re-waits (vmcnt(0)) for those loads before every use,
@@ -913,22 +957,29 @@ static hipError_t launch_g(ConvArgs a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int NS>
+template <int BM, int BN, int KG, int NS>
+constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
+
+template <int BM, int BN, int KG, int NS>
 static hipError_t launch_stream(ConvArgs a, hipStream_t st)
 {
-    a.tiles_m = (a.M + 63) / 64, a.tiles_n = a.Npad / 64;
+    if (a.cpt % KG != 0 || a.Npad % BN != 0) return hipErrorInvalidValue;
+    a.cpt /= KG;  // the kernel counts K in steps of KG chunks
+    a.tiles_m = (a.M + BM - 1) / BM, a.tiles_n = a.Npad / BN;
     auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     a.mg_wo = magic(a.Wo), a.mg_ho = magic(a.Ho), a.mg_tn = magic(a.tiles_n), a.mg_tm = magic(a.tiles_m);
     a.mg_ks = magic(a.ksplit), a.mg_cpt = magic(a.cpt);
     a.items = a.tiles_m * a.tiles_n * a.nphase * a.ksplit;
-    // two workgroups per CU at most: more tiles than that are walked by the same workgroups (VNECT_MAXWG: tuning)
-    static const int maxwg = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 512;
+    // two workgroups per CU at most (one for the K-group shapes: their ring fills the LDS): more tiles than that are
+    // walked by the same workgroups (VNECT_MAXWG: tuning)
+    static const int maxwg_env = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 0;
+    const int maxwg = maxwg_env > 0 ? maxwg_env : (KG == 1 ? 512 : 256);
     dim3 grid(a.items < maxwg ? a.items : maxwg);
-    size_t lds = (size_t)NS * 128 * 32 * sizeof(float);
+    const size_t lds = stream_lds<BM, BN, KG, NS>();
     // profiling twin: start / end stamps only, or (VNECT_PROF_DETAIL=1, tools/phase_table.py) the per-phase stamps too
     static const bool detail = getenv("VNECT_PROF_DETAIL") && atoi(getenv("VNECT_PROF_DETAIL")) != 0;
     const int prof = a.prof ? (detail ? 2 : 1) : 0;
-#define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<NS, BF, PR>), grid, dim3(512), lds, st, a)
+#define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a)
     if (a.bf16) {
         if (prof == 0) LAUNCH_STREAM(true, 0);
         else if (prof == 1) LAUNCH_STREAM(true, 1);
@@ -940,6 +991,25 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     }
 #undef LAUNCH_STREAM
     return hipGetLastError();
+}
+
+template <int BM, int BN, int KG, int NS>
+static hipError_t setup_stream()
+{
+    hipFuncAttributes fa;
+    for (const void* f : {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 0>,
+                          (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 1>,
+                          (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>}) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());
+        if (e != hipSuccess) return e;
+        e = hipFuncGetAttributes(&fa, f);
+        if (e != hipSuccess) return e;
+        // the launch plan assumes two workgroups per CU (one for the K-group shapes): refuse a build that needs more registers
+        // or scratch (the per-phase tuning twins, PROF = 2, may spill a few bytes)
+        const bool twin = f == (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2> || f == (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>;
+        if (fa.numRegs > (KG == 1 ? 128 : 256) || (fa.localSizeBytes != 0 && !twin)) return hipErrorLaunchOutOfResources;
+    }
+    return hipSuccess;
 }
 
 // Ring depths leave room for two workgroups per CU (<= 80 KiB each): measured faster than one deep ring per CU
@@ -956,21 +1026,13 @@ hipError_t conv_setup()
     if (e != hipSuccess) return e;
     SETG(64, 64, 5) SETG(128, 64, 3) SETG(64, 128, 3)
 #undef SETG
-    // two workgroups per CU is what the launch plan assumes: refuse a build that needs more than 128 VGPRs or scratch
-    hipFuncAttributes fa;
-    for (const void* f : {(const void*)conv_stream_kernel<5, false, 0>, (const void*)conv_stream_kernel<5, true, 0>,
-                          (const void*)conv_stream_kernel<5, false, 1>, (const void*)conv_stream_kernel<5, true, 1>,
-                          (const void*)conv_stream_kernel<5, false, 2>, (const void*)conv_stream_kernel<5, true, 2>}) {
-        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 128 * 32 * 4);
-        if (e != hipSuccess) return e;
-        e = hipFuncGetAttributes(&fa, f);
-        if (e != hipSuccess) return e;
-        if (fa.numRegs > 128 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
-    }
+    if ((e = setup_stream<64, 64, 1, 5>()) != hipSuccess) return e;
+    if ((e = setup_stream<64, 32, 2, 5>()) != hipSuccess) return e;
+    if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
-hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
+hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st)
 {
     const int epr = a.bf16 ? 64 : 32;
     if (a.Npad % BN != 0 || a.K != a.ntaps * a.cpt * epr || a.nphase * a.ntaps > MAX_TAPS ||
@@ -979,7 +1041,10 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st)
     // range of the multiply-high divisions in the kernel (x / d exact while x * d < 2^32)
     if ((long long)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1ll << 32) || a.M >= (1 << 24)) return hipErrorInvalidValue;
     static const bool stream = !(getenv("VNECT_STREAM") && atoi(getenv("VNECT_STREAM")) == 0);  // A/B against one tile per workgroup
-    if (BM == 64 && BN == 64 && stream) return launch_stream<5>(a, st);
+    if (KG == 2 && BM == 64 && BN == 32) return launch_stream<64, 32, 2, 5>(a, st);
+    if (KG == 4 && BM == 32 && BN == 32) return launch_stream<32, 32, 4, 4>(a, st);
+    if (KG != 1) return hipErrorInvalidValue;
+    if (BM == 64 && BN == 64 && stream) return launch_stream<64, 64, 1, 5>(a, st);
     if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);  // a 3-stage ring (3 workgroups per CU) was measured: no gain
     if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
     if (BM == 64 && BN == 128) return launch_g<64, 128, 3>(a, st);

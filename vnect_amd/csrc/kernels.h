@@ -69,7 +69,7 @@ struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])
     int bf16, out_f32;
 };
 
-hipError_t launch_conv(const ConvArgs& a, int BM, int BN, hipStream_t st);
+hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st);  // KG: in-workgroup K groups (1, 2, 4)
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
 hipError_t conv_setup();  // one-time function attributes (dynamic LDS size)
 

@@ -42,7 +42,7 @@ struct Layer {
     int in = -1, resid = -1, out = -1, out2 = -1;
     ConvArgs a{};
     ReduceArgs r{};
-    int BM = 64, BN = 64;
+    int BM = 64, BN = 64, KG = 1;  // tile shape; KG = in-workgroup K groups (conv.hip)
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     int Nreal = 0, Kreal = 0;
     double flops = 0;
@@ -372,21 +372,28 @@ void choose_tile(Layer& L, long long npix)
     (void)npix;
     const int nch = L.a.ntaps * L.a.cpt;
     const int kel = L.a.K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
-    int BM = 64, BN = 64, ks = 1;
-    const long long tiles = (long long)((L.a.M + 63) / 64) * (round_up(L.Nreal, 64) / 64) * L.a.nphase;
+    int BM = 64, BN = 64, KG = 1, ks = 1;
+    const long long mt = (L.a.M + 63) / 64, nreal = L.Nreal;
+    const long long tiles = mt * (round_up((int)nreal, 64) / 64) * L.a.nphase;
     if (L.a.bf16) {  // bf16 loops are 2-3x shorter: the extra reduce launch only pays for the smallest, deepest layer
         if (tiles <= 64 && kel >= 2048) ks = std::min(5, nch);
     } else if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
-        ks = std::min(5, nch);
+        // Too few 64x64 tiles for 256 CUs and a long K: split K.  Inside the workgroup where that alone fills the chip
+        // (one workgroup per CU, four K-parallel or M/N-parallel accumulators: no slabs, no reduce launch) ...
+        const long long t64x32 = mt * (round_up((int)nreal, 32) / 32) * L.a.nphase;
+        const long long t32x32 = ((L.a.M + 31) / 32) * (round_up((int)nreal, 32) / 32) * L.a.nphase;
+        if (t64x32 > 128 && t64x32 <= 256 && L.a.cpt % 2 == 0) BM = 64, BN = 32, KG = 2;
+        else if (t32x32 > 128 && t32x32 <= 256 && L.a.cpt % 4 == 0) BM = 32, BN = 32, KG = 4;
+        else ks = std::min(5, nch);  // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel
     }
     const char* force = getenv("VNECT_FORCE_TILE");
     if (force) {
         int fBM = 0, fBN = 0, fks = 0;
         if (sscanf(force, "%d,%d,%d", &fBM, &fBN, &fks) == 3 && fks >= 1 && fks <= 8 &&
             ((fBM == 64 && fBN == 64) || (fBM == 128 && fBN == 64) || (fBM == 64 && fBN == 128)))
-            BM = fBM, BN = fBN, ks = std::min(fks, nch);
+            BM = fBM, BN = fBN, KG = 1, ks = std::min(fks, nch);
     }
-    L.BM = BM, L.BN = BN, L.a.ksplit = ks;
+    L.BM = BM, L.BN = BN, L.KG = KG, L.a.ksplit = ks;
 }
 
 struct ConvSpec {
@@ -496,7 +503,7 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     a.Nvalid = L.Nreal;
     L.flops = 2.0 * a.M * (double)cin * L.Nreal;
     choose_tile(L, (long long)a.M);
-    if (L.BN != 64 || L.a.ksplit != 1) L.BM = 64, L.BN = 64, L.a.ksplit = 1;  // the column split relies on 64-wide tiles, no slabs
+    if (L.BN != 64 || L.a.ksplit != 1 || L.KG != 1) L.BM = 64, L.BN = 64, L.KG = 1, L.a.ksplit = 1;  // the column split relies on 64-wide tiles, no slabs
     a.Npad = round_up(L.Nreal, 64);
     std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
     for (int ci = 0; ci < cin; ci++) {
@@ -792,7 +799,7 @@ int run_network(vnect_handle* h, bool timed)
         if (L.op == OP_CONV) {
             ConvArgs a = L.a;
             a.prof = timed ? h->d_prof + PROF_SLOTS * (&L - h->layers.data()) : nullptr;
-            HIPCK(h, launch_conv(a, L.BM, L.BN, h->st));
+            HIPCK(h, launch_conv(a, L.BM, L.BN, L.KG, h->st));
             if (L.a.ksplit > 1) HIPCK(h, launch_reduce(L.r, h->st));
         } else if (L.op == OP_POOL) {
             const Tensor &i = h->tensors[L.in], &o = h->tensors[L.out];
