@@ -132,7 +132,7 @@ def main():
     out = None
     tim = None
     if rank == 0 or args.pyramid:  # pyramid: every inference is collective, so every rank must take part
-        # Dominant kernel = vnect::conv_stream_kernel<5,BF> (the whole conv stack).
+        # Dominant kernel = vnect::conv_stream_kernel<BM,BN,KG,NS,BF,PROF> (the whole conv stack).
         # Its launch durations are taken live from a profiling twin of the frame graph in which every conv
         # kernel stamps its first-wave start and last-wave end with the 100 MHz device clock (what rocprofv3's
         # kernel trace reports); HIP events on the library's stream bracket the whole replayed frame.
@@ -151,6 +151,12 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get("hbm_bytes_per_frame")
+        # rocprofv3's average for the same kernels (committed summary of the same command): its durations run from the
+        # dispatch packet to the completion signal, i.e. ~1.5-2 us per launch more than first-wave-start .. last-wave-end
+        rocprof_us = None
+        rj = os.path.join(ROOT, "profiles", "r01_conv_roofline.json" if args.precision == "fp32" else "r01_conv_roofline_bf16.json")
+        if os.path.exists(rj):
+            rocprof_us = json.load(open(rj)).get("conv_avg_us_per_launch")
         peak = PEAK_FP32_MFMA if args.precision == "fp32" else PEAK_BF16_MFMA
         ms = elapsed / args.steps * 1e3
         out = {
@@ -177,10 +183,12 @@ def main():
                              "algorithmic_bytes_per_frame": BF16_BYTES_PER_FRAME,
                              "mfma_view": {"achieved_tflops": round(achieved, 2), "peak": PEAK_BF16_MFMA,
                                            "frac": round(achieved / PEAK_BF16_MFMA, 4)}}),
-                         kernel="vnect::conv_stream_kernel<5,%s> (64x64 tiles, 5-stage LDS ring; %d launches per frame)"
+                         kernel="vnect::conv_stream_kernel<BM,BN,KG,NS,%s,0>: 64x64x1 (5-stage LDS ring), 64x32x2 and 32x32x4 "
+                                "(in-workgroup K groups) on the 23x23 layers; %d launches per frame"
                                 % ("false" if args.precision == "fp32" else "true", tim["conv_launches"]),
                          launches_per_frame=tim["conv_launches"],
                          avg_launch_us=round(conv_ms * 1e3 / tim["conv_launches"], 3),
+                         rocprofv3_avg_launch_us=None if rocprof_us is None else round(rocprof_us, 3),
                          kernel_ms_per_frame=round(conv_ms, 4), flops_per_frame=FLOPS_PER_FRAME,
                          conv_stack_span_ms=round(tim["net_ms"] / nprof, 4),
                          hip_event_frame_ms=round(tim["total_ms"] / nprof, 4),

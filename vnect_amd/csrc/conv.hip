@@ -5,11 +5,10 @@
 // of src/vnect_model.py:25-217: Conv2D(+BiasAdd+Add+Relu), Conv2DBackpropInput (as 4 sub-pixel phases),
 // FusedBatchNorm (folded into the epilogue), MaxPool, and the bone-length Mul/Add/Sqrt/Concat.
 //
-// Tiling: one 512-thread workgroup computes a BM x BN output tile: 4 consumer waves (2x2, one per SIMD) own
-// (BM/2)x(BN/2) each as 32x32 MFMA accumulators, 4 producer waves feed them.  K runs in 32-float chunks: a
-// chunk is one filter tap and 32 consecutive input channels, i.e. one 128-byte run per NHWC input pixel, so
-// global reads are whole cache lines.  A (gathered activation rows) and B (pre-packed weights, [N][K])
-// chunks go global -> LDS by LDS-DMA into a ring of stages (details at the kernel).
+// Tiling: a 512-thread workgroup = 4 consumer waves (one per SIMD, one 32x32 MFMA accumulator each) + 4 producer
+// waves.  K runs in 32-float chunks: a chunk is one filter tap and 32 consecutive input channels, i.e. one 128-byte
+// run per NHWC input pixel, so global reads are whole cache lines.  A (gathered activation rows) and B (pre-packed
+// weights, [N][K]) chunks go global -> LDS by buffer-addressed LDS-DMA into a ring of stages (details at the kernel).
 #include "kernels.h"
 
 #include <cstdlib>
@@ -22,19 +21,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LDT = 36;  // LDS row pitch in floats (32 + 4)
-
 // ---------------------------------------------------------------------------------------------------------
-// Chunks go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into
-// an NS-deep ring, issued NS-1 chunks ahead with counted vmcnt waits, one raw s_barrier per chunk.  The LDS
-// image is lane-linear per wave-instruction (8 rows x 128 B); bank conflicts are removed by fetching, for LDS
-// slot (row r, 16-B unit u'), the SOURCE unit u = u' ^ ((r >> 1) & 7) and applying the same XOR on the
-// fragment reads: a ds_read_b128 lane group (16 distinct rows, one unit) then covers all 16 slots of the
-// 256-B bank row.  Out-of-image taps and rows past M read a zero page instead of branching.
-#define GLDS16(gp, lp)                                                                          \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),      \
-                                     (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
-
+// The LDS image of a chunk is lane-linear per LDS-DMA instruction (8 rows x 128 B).  Bank conflicts are removed by
+// fetching, for LDS slot (row r, 16-B unit u'), the SOURCE unit u = u' ^ ((r >> 1) & 7) and applying the same XOR on
+// the fragment reads: a ds_read_b128 lane group (16 distinct rows, one unit) then covers all 16 slots of the 256-B
+// bank row.  Chunks are issued NS-1 ahead with counted vmcnt waits; one raw s_barrier per chunk.
 template <int N>
 __device__ __forceinline__ void wait_vm()
 {
@@ -44,396 +35,6 @@ __device__ __forceinline__ void wait_vm()
 // x / d for 0 <= x, x * d < 2^32, with mg = ceil(2^32 / d) (d == 1: mg wraps to 0, handled); one v_mul_hi instead of
 // the ~35-instruction integer division sequence, which sat on every workgroup's critical path before its first load
 __device__ __forceinline__ int fdiv(int x, unsigned mg, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, mg); }
-
-// BF = false: fp32 operands, v_mfma_f32_32x32x2_f32 (exact f32), a 128-B LDS row holds 32 K-elements.
-// BF = true : bf16 operands (activations and weights stored as bf16, fp32 accumulate), v_mfma_f32_32x32x16_bf16,
-//             a 128-B row holds 64 K-elements, so the same ring / swizzle / fragment addressing moves twice the K
-//             per byte: lane half h of MFMA step q reads the 16-B unit 2q+h = k 16q+8h..+7 of its row.
-template <int BM, int BN, int NS, bool BF>
-__global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a)
-{
-    using T = typename std::conditional<BF, __bf16, float>::type;
-    constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
-    constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
-    constexpr int STAGE = (BM + BN) * 32;  // floats per ring stage (128-B rows, no padding)
-    constexpr int NLD = AR + BR;           // LDS-DMA instructions per thread per chunk
-    static_assert(NS >= 3 && NS <= 9, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    // Wave specialisation: waves 0-3 are CONSUMERS (one per SIMD: fragment reads + MFMA + epilogue), waves 4-7 are
-    // PRODUCERS (one per SIMD: LDS-DMA issue + landing waits).  An LDS-DMA instruction costs its wave ~100-200
-    // issue cycles; in a wave that also owns the MFMA chain that stall idles the matrix pipe, in a partner wave
-    // it does not.  All 8 waves meet at one s_barrier per 32-deep chunk.
-    // The ~360-byte argument block spans six scalar-cache lines and the compiler loads its fields where they are first
-    // used: one scalar-cache round trip after another (cold: measured 1.7 us from wave start to the first LDS-DMA;
-    // even as hits ~0.15 us each).  Touch every line now, back to back, then pin the fields the prologue needs in
-    // SGPRs so they are fetched as a few wide loads with a single wait.
-    {
-        typedef __attribute__((address_space(4))) const int kint;
-        kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
-        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80], k6 = kp[96];
-        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6));
-    }
-    struct Hot {
-        const float *in, *w, *bias, *resid, *zeros;
-        unsigned long long* prof;
-        int H, W, Cs, Ho, Wo, M, K, ntaps, cpt, stride, Nvalid, Npad, ldr, ksplit, pixmode, tiles_m, tiles_n;
-        unsigned mg_wo, mg_ho, mg_tn, mg_tm;
-        long long w_phase_stride;
-    } h = {a.in, a.w, a.bias, a.resid, a.zeros, a.prof, a.H, a.W, a.Cs, a.Ho, a.Wo, a.M, a.K, a.ntaps, a.cpt, a.stride, a.Nvalid,
-           a.Npad, a.ldr, a.ksplit, a.pixmode, a.tiles_m, a.tiles_n, a.mg_wo, a.mg_ho, a.mg_tn, a.mg_tm, a.w_phase_stride};
-    asm volatile("" : "+s"(h.in), "+s"(h.w), "+s"(h.bias), "+s"(h.resid), "+s"(h.prof), "+s"(h.zeros), "+s"(h.H), "+s"(h.W),
-                 "+s"(h.Cs), "+s"(h.Ho), "+s"(h.Wo), "+s"(h.M), "+s"(h.K), "+s"(h.ntaps), "+s"(h.cpt), "+s"(h.stride));
-    asm volatile("" : "+s"(h.Nvalid), "+s"(h.Npad), "+s"(h.ldr), "+s"(h.ksplit), "+s"(h.pixmode), "+s"(h.tiles_m), "+s"(h.tiles_n),
-                 "+s"(h.mg_wo), "+s"(h.mg_ho), "+s"(h.mg_tn), "+s"(h.mg_tm), "+s"(h.w_phase_stride));
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const bool producer = threadIdx.x >= 256;
-    const int wm = wave >> 1, wn = wave & 1;
-    // profiling twin only: the first 8 workgroups (first dispatched) stamp the start, every workgroup its end
-    // into one of 8 slots (one address would serialise ~1600 atomics)
-    if (h.prof && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(h.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    // phase stamps of workgroup 0 (slots 9-13) and the start of the last-dispatched workgroups (slot 15): tuning aid
-    const bool pstamp = h.prof && threadIdx.x == 0 && blockIdx.x == 0;
-    if (pstamp) h.prof[9] = __builtin_amdgcn_s_memrealtime();
-    if (h.prof && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(h.prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    // XCD-aware tile order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs,
-    // so give every XCD a contiguous run of the logical tile sequence (N-tile fastest, then M, then K-slice /
-    // phase): tiles that share an activation row block, and all weight tiles, then meet in one XCD's L2.
-    // Bijective for any grid size.  (A row-band-per-XCD order that keeps each XCD on the rows it wrote one layer
-    // earlier was measured too: no gain -- operand residency is not what limits this kernel -- and it unbalances
-    // layers with few M tiles.)
-    int tile_m, tile_n, zz;
-    {
-        const int nwg = gridDim.x, id = blockIdx.x;
-        const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
-        const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
-        const int t2 = fdiv(logical, h.mg_tn, h.tiles_n);
-        tile_n = logical - t2 * h.tiles_n;
-        zz = fdiv(t2, h.mg_tm, h.tiles_m);
-        tile_m = t2 - zz * h.tiles_m;
-    }
-    if (pstamp) h.prof[20] = __builtin_amdgcn_s_memrealtime();
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int phase = zz / h.ksplit, ks = zz - phase * h.ksplit;
-    const int nch = h.ntaps * h.cpt;
-    const int c0 = (int)(((long long)nch * ks) / h.ksplit);
-    const int c1 = (int)(((long long)nch * (ks + 1)) / h.ksplit);
-    const int total = c1 - c0;
-    const int srow = tid >> 3;
-    const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
-    const int pix = h.pixmode;
-
-    int a_iy[AR], a_ix[AR], a_pix[AR];
-#pragma unroll
-    for (int i = 0; i < AR; i++) {
-        int m = m0 + srow + 32 * i;
-        if (m < h.M) {
-            const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
-            const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
-            // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
-            a_iy[i] = oy * h.stride + (pix && BF ? unit >> 2 : 0);
-            a_ix[i] = ox * h.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
-            a_pix[i] = s * h.H * h.W;
-        } else {
-            a_iy[i] = -(1 << 20);
-            a_ix[i] = 0;
-            a_pix[i] = 0;
-        }
-    }
-    const T* __restrict__ inp = (const T*)h.in;
-    const T* __restrict__ zero = (const T*)h.zeros;
-    const T* __restrict__ wp =
-        (const T*)h.w + (long long)phase * h.w_phase_stride + (long long)(n0 + srow) * h.K + unit * EPU + (long long)c0 * EPR;
-    const int* dyp = a.dy + phase * h.ntaps;
-    const int* dxp = a.dx + phase * h.ntaps;
-
-    int tap = c0 / h.cpt, cc = c0 - tap * h.cpt;
-    int a_off[AR];
-    bool a_ok[AR];
-    auto set_tap = [&](int t) {
-        const int dy = dyp[t], dx = dxp[t];
-#pragma unroll
-        for (int i = 0; i < AR; i++) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            a_ok[i] = (unsigned)iy < (unsigned)h.H && (unsigned)ix < (unsigned)h.W;
-            a_off[i] = (a_pix[i] + iy * h.W + ix) * h.Cs + (pix ? 0 : unit * EPU);
-        }
-    };
-    auto issue = [&](int stage) {
-        float* sb = smem + stage * STAGE + wave * (8 * 32);  // wave-uniform; the hardware adds lane * 16 B
-#pragma unroll
-        for (int i = 0; i < AR; i++) {
-            const T* src = a_ok[i] ? inp + a_off[i] + cc * EPR : zero;
-            GLDS16(src, sb + i * (32 * 32));
-        }
-#pragma unroll
-        for (int i = 0; i < BR; i++) GLDS16(wp + (long long)i * 32 * h.K, sb + BM * 32 + i * (32 * 32));
-        wp += EPR;
-        if (++cc == h.cpt) {
-            cc = 0;
-            if (++tap < h.ntaps) set_tap(tap);
-        }
-    };
-    // all but the `young` youngest chunks (NLD instructions each) have landed in LDS
-    auto wait_landed = [&](int young) {
-        switch (young) {
-            case 1: wait_vm<NLD>(); break;
-            case 2: wait_vm<2 * NLD>(); break;
-            case 3: wait_vm<3 * NLD>(); break;
-            case 4: wait_vm<4 * NLD>(); break;
-            case 5: wait_vm<5 * NLD>(); break;
-            case 6: wait_vm<6 * NLD>(); break;
-            case 7: wait_vm<7 * NLD>(); break;
-            default: wait_vm<0>(); break;
-        }
-    };
-
-    if (pstamp) h.prof[21] = __builtin_amdgcn_s_memrealtime();
-    // shortcut tile: loaded now (ordinary loads, ahead of the LDS-DMA queue) so the epilogue never waits for it
-    const bool fused = h.ksplit == 1;
-    const bool has_res = fused && h.resid != nullptr && !producer;
-    const int nlim = fused ? h.Nvalid : h.Npad;
-    const int erow = lane >> 3, ecol = (lane & 7) * 4;
-    f32x4 rs[TM][TN][4];
-    f32x4 bpre[TN];  // bias of this wave's columns, requested now for the same reason
-    if (fused && !producer) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) bpre[j] = *(const f32x4*)(h.bias + n0 + wn * WN + j * 32 + ecol);
-    }
-    if (has_res) {
-        const float* __restrict__ resid = h.resid;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int m = m0 + wm * WM + i * 32 + erow + 8 * k;
-                    const int n = n0 + wn * WN + j * 32 + ecol;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (m < h.M && n < nlim) {  // shortcut layers: os == 1
-                        if constexpr (BF) v = __builtin_convertvector(*(const bf16x4*)((const __bf16*)resid + (long long)m * h.ldr + n), f32x4);
-                        else v = *(const f32x4*)(resid + (long long)m * h.ldr + n);
-                    }
-                    rs[i][j][k] = v;
-                }
-    }
-
-    if (pstamp) h.prof[22] = __builtin_amdgcn_s_memrealtime();
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    // fragment addresses: row lane&31 of the wave tile, unit (2q + h) ^ ((row >> 1) & 7)
-    int fo[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) fo[q] = (lane & 31) * 32 + (((2 * q + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4);
-    auto rfrag = [&](int stage, int q, f32x4(&af)[TM], f32x4(&bf)[TN]) {
-        const float* Ab = smem + stage * STAGE + (wm * WM) * 32 + fo[q];
-        const float* Bb = smem + stage * STAGE + (BM + wn * WN) * 32 + fo[q];
-#pragma unroll
-        for (int i = 0; i < TM; i++) af[i] = *(const f32x4*)(Ab + i * (32 * 32));
-#pragma unroll
-        for (int j = 0; j < TN; j++) bf[j] = *(const f32x4*)(Bb + j * (32 * 32));
-    };
-    auto mma = [&](const f32x4(&af)[TM], const f32x4(&bf)[TN]) {
-        if constexpr (BF) {
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                       __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    if (pstamp) h.prof[23] = __builtin_amdgcn_s_memrealtime();
-    if (producer) {
-        // ---- producer waves: keep NS-1 chunks in flight, publish chunk t+1 at barrier t --------------------
-        // With MFMAs running, a CU retires only ~one LDS-DMA instruction per 70 cycles (tools/mfma_lds.hip): the
-        // producers, not the MFMA chain, pace a 64x64 tile.  They get issue priority; the dependent MFMA chain only
-        // needs one issue slot per 64 cycles.
-        __builtin_amdgcn_s_setprio(3);
-        set_tap(tap);
-#pragma unroll
-        for (int p = 0; p < NS - 1; p++)
-            if (p < total) issue(p);
-        wait_landed(total - 1 < NS - 2 ? total - 1 : NS - 2);
-        __builtin_amdgcn_s_barrier();  // chunk 0 visible
-        int stage = 0;
-        const bool pacct = h.prof && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
-        long long pw = 0, pb = 0, pi = 0;
-        for (int t = 0; t < total; t++) {  // one barrier per chunk, also after the last one (keeps the consumer loop branch-free)
-            // chunk t+1 complete in LDS; younger chunks still in flight: t+2 .. min(t+NS-2, total-1)
-            const int young = total - 2 - t;
-            const long long q0 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
-            wait_landed(young < NS - 3 ? young : NS - 3);
-            const long long q1 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
-            __builtin_amdgcn_s_barrier();  // consumers are past chunk t-1: its stage may be refilled
-            const long long q2 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
-            if (t + NS - 1 < total) issue(stage == 0 ? NS - 1 : stage - 1);
-            const long long q3 = h.prof ? __builtin_amdgcn_s_memtime() : 0;
-            pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
-            stage = stage + 1 == NS ? 0 : stage + 1;
-        }
-        if (pacct) h.prof[16] = pw, h.prof[17] = pb, h.prof[18] = pi;
-        __builtin_amdgcn_s_barrier();  // matches the consumers' ring-is-dead barrier
-        return;
-    }
-
-    // ---- consumer waves ------------------------------------------------------------------------------------
-    // All fragments of chunk t+1 (8 x ds_read_b128 for a 32x32 wave tile) are requested right after the barrier
-    // that publishes it, i.e. half a chunk of MFMAs before their first use; two register sets alternate.
-    struct Frag {
-        f32x4 a[4][TM], b[4][TN];
-    };
-    Frag F0, F1;
-    auto rall = [&](int stg, Frag& F) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) rfrag(stg, q, F.a[q], F.b[q]);
-    };
-    int stage = 0;
-    long long cbw = 0;  // profiling twin: cycles consumer wave 0 waits at the per-chunk barrier
-    // One chunk = 16 MFMAs per accumulator.  The reads of chunk t+1 are issued ONE PER MFMA behind the barrier:
-    // a wave issues in order, and eight back-to-back ds_read_b128 hold its issue slot for ~35 cycles each when
-    // four waves read at once (tools/lds_read.hip) -- behind an MFMA that time is free, in a burst it is not.
-    auto step = [&](Frag& cur, Frag& nxt, int t) {
-        const int nstage = stage + 1 == NS ? 0 : stage + 1;
-        mma(cur.a[0], cur.b[0]);
-        mma(cur.a[1], cur.b[1]);
-        // after the last chunk the barrier and the reads still run (the reads fetch stale ring data that is never
-        // used): no branch sits between the MFMAs
-        if (h.prof) {
-            const long long b0 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_barrier();
-            cbw += __builtin_amdgcn_s_memtime() - b0;
-        } else
-        __builtin_amdgcn_s_barrier();  // chunk t+1 visible; every consumer is past chunk t-1
-        if constexpr (TM == 1 && TN == 1 && !BF) {
-            const float* Ab = smem + nstage * STAGE + (wm * WM) * 32;
-            const float* Bb = smem + nstage * STAGE + (BM + wn * WN) * 32;
-#pragma unroll
-            for (int q = 2; q < 4; q++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][0][e], cur.b[q][0][e], acc[0][0], 0, 0, 0);
-                    const int r = (q - 2) * 4 + e;  // 0..7: fragment r>>1 of A (even r) or B (odd r)
-                    if (r & 1) nxt.b[r >> 1][0] = *(const f32x4*)(Bb + fo[r >> 1]);
-                    else nxt.a[r >> 1][0] = *(const f32x4*)(Ab + fo[r >> 1]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one DS read
-                }
-        } else {
-            rall(nstage, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(cur.a[2], cur.b[2]);
-            mma(cur.a[3], cur.b[3]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stage = nstage;
-    };
-    if (pstamp) h.prof[10] = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_barrier();  // chunk 0 visible
-    if (pstamp) h.prof[11] = __builtin_amdgcn_s_memrealtime();
-    rall(0, F0);
-    for (int t = 0; t < total; t += 2) {
-        step(F0, F1, t);
-        if (t + 1 < total) step(F1, F0, t + 1);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // ring is dead: reuse it as the epilogue scratch
-    if (pstamp) h.prof[12] = __builtin_amdgcn_s_memrealtime(), h.prof[19] = cbw;
-
-    // Epilogue.  C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Each 32x32 accumulator goes
-    // through a wave-private LDS scratch so that global traffic is 16 B per lane along N (8 lanes = one 128-B line).
-    const int py = phase >> 1, px = phase & 1;
-    const bool direct = (a.os == 1);
-    // Two layers that read the same input run as one GEMM (columns [0, split_n) -> out, the rest -> out2): the whole
-    // 64-wide tile lies on one side because split_n is a multiple of the tile width.
-    const bool second = fused && a.out2 != nullptr && n0 >= a.split_n;
-    float* __restrict__ outp = !fused ? a.ws + (long long)ks * a.slab_pix * h.Npad : (second ? a.out2 : a.out);
-    const int ncol0 = second ? a.split_n : 0;  // first column of the tensor written by this tile
-    const int ldo = !fused ? h.Npad : (second ? a.ldc2 : a.ldc);
-    const bool of32 = !BF || !fused || a.out_f32;  // split-K slabs and the final maps stay fp32
-    float* scr = smem + wave * (32 * LDT);
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * WN + j * 32 + ecol;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, s4 = {1.f, 1.f, 1.f, 1.f}, h4 = {0.f, 0.f, 0.f, 0.f};
-        if (fused) {
-            b4 = bpre[j];
-            if (a.scale) s4 = *(const f32x4*)(a.scale + n), h4 = *(const f32x4*)(a.shift + n);
-        }
-        const bool vec = n + 3 < nlim;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                scr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[i][j][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int row = erow + 8 * k;
-                const int m = m0 + wm * WM + i * 32 + row;
-                f32x4 o = *(const f32x4*)&scr[row * LDT + ecol];
-                long long op = m;
-                if (!direct) {
-                    const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
-                    const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
-                    op = ((long long)s * a.OH + oy * a.os + py) * a.OW + ox * a.os + px;
-                }
-                if (fused) {
-                    o = o + b4;
-                    if (a.scale) o = o * s4 + h4;
-                    if (has_res) o = o + rs[i][j][k];
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (n + e < a.relu_cols) o[e] = o[e] > 0.f ? o[e] : 0.f;
-                }
-                if (!(m < h.M && n < nlim)) continue;
-                if (of32) {
-                    float* dst = outp + op * ldo + (n - ncol0);
-                    if (vec) {
-                        *(f32x4*)dst = o;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (n + e < nlim) dst[e] = o[e];
-                    }
-                } else {
-                    __bf16* dst = (__bf16*)outp + op * ldo + (n - ncol0);
-                    const bf16x4 ob = __builtin_convertvector(o, bf16x4);  // round to nearest even (v_cvt_pk_bf16_f32)
-                    if (vec) {
-                        *(bf16x4*)dst = ob;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (n + e < nlim) dst[e] = ob[e];
-                    }
-                }
-            }
-        }
-    }
-    if (h.prof && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
-        if (pstamp) h.prof[13] = __builtin_amdgcn_s_memrealtime();
-        atomicMax(h.prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    }
-}
 
 // Pointers that went through an SGPR pin (inline asm) lose their address space; accesses through them would be FLAT
 // (counted on vmcnt AND lgkmcnt, so the compiler waits for each store before the next: measured 2.5-5 us per epilogue).
@@ -493,7 +94,8 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    {   // argument block: touch every scalar-cache line at once (see conv_glds_kernel)
+    {   // The ~400-byte argument block spans seven scalar-cache lines and the compiler loads fields where they are first
+        // used, one scalar-cache round trip after another (cold: 1.7 us from wave start to the first LDS-DMA): touch every line now
         typedef __attribute__((address_space(4))) const int kint;
         kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
         const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80], k6 = kp[96];
@@ -551,7 +153,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         it.m0 = tile_m * BM, it.n0 = tile_n * BN;
         if (h.ksplit == 1) {
             it.c0 = 0, it.cnt = nch;
-        } else {  // same slice boundaries as conv_glds_kernel
+        } else {  // K slice ks of ksplit: [nch*ks/ksplit, nch*(ks+1)/ksplit)
             it.c0 = (nch * it.ks) / h.ksplit;
             it.cnt = (nch * (it.ks + 1)) / h.ksplit - it.c0;
         }
@@ -588,7 +190,6 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         const srd_t srdA = make_srd((const char*)p.in - p.tap_bias), srdB = make_srd(p.w);
         const int srow = tid >> 3;
         const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
-        constexpr unsigned OOB = 0x80000000u;
         unsigned a_vo[ARB], a_mask[ARB], a_cur[ARB], b_vo[BRB];
         unsigned soA = 0, soB = 0;
         int tb = 0;  // first tap-table entry of the item's phase (indexing the argument block directly keeps it in constant memory)
@@ -850,7 +451,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                        "+v"(rs[6]), "+v"(rs[7]), "+v"(rs[8]), "+v"(rs[9]), "+v"(rs[10]), "+v"(rs[11]), "+v"(rs[12]), "+v"(rs[13]),
                        "+v"(rs[14]), "+v"(rs[15]));
         const int py = it.phase >> 1, px = it.phase & 1;
-        const bool second = fused && c.out2 != nullptr && it.n0 >= c.split_n;  // two layers sharing one input: see conv_glds_kernel
+        const bool second = fused && c.out2 != nullptr && it.n0 >= c.split_n;  // two layers sharing one input run as one GEMM: columns [0, split_n) -> out, the rest -> out2 (split_n is a multiple of the tile width)
         gfloat* outp = (gfloat*)(!fused ? c.ws + (long long)it.ks * c.slab_pix * c.Npad : (second ? c.out2 : c.out));
         const int ncol0 = second ? c.split_n : 0;
         const int ldo = !fused ? c.Npad : (second ? c.ldc2 : c.ldc);
@@ -944,19 +545,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
     }
 }
 
-template <int BM, int BN, int NS>
-static hipError_t launch_g(ConvArgs a, hipStream_t st)
-{
-    a.tiles_m = (a.M + BM - 1) / BM, a.tiles_n = a.Npad / BN;
-    auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
-    a.mg_wo = magic(a.Wo), a.mg_ho = magic(a.Ho), a.mg_tn = magic(a.tiles_n), a.mg_tm = magic(a.tiles_m);
-    dim3 grid(a.tiles_m * a.tiles_n * a.nphase * a.ksplit);
-    size_t lds = (size_t)NS * (BM + BN) * 32 * sizeof(float);
-    if (a.bf16) hipLaunchKernelGGL((conv_glds_kernel<BM, BN, NS, true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv_glds_kernel<BM, BN, NS, false>), grid, dim3(512), lds, st, a);
-    return hipGetLastError();
-}
-
 template <int BM, int BN, int KG, int NS>
 constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
 
@@ -1012,20 +600,11 @@ static hipError_t setup_stream()
     return hipSuccess;
 }
 
-// Ring depths leave room for two workgroups per CU (<= 80 KiB each): measured faster than one deep ring per CU
-// on every layer of the network (tools/sweep.sh).
+// Ring depths: 5 x 16 KiB leaves room for two 64x64 workgroups per CU (measured faster than one deeper ring on every
+// layer); the K-group shapes run one workgroup per CU.
 hipError_t conv_setup()
 {
     hipError_t e;
-#define SETG(BM, BN, NS)                                                                                       \
-    e = hipFuncSetAttribute((const void*)conv_glds_kernel<BM, BN, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            NS * (BM + BN) * 32 * (int)sizeof(float));                                          \
-    if (e != hipSuccess) return e;                                                                              \
-    e = hipFuncSetAttribute((const void*)conv_glds_kernel<BM, BN, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            NS * (BM + BN) * 32 * (int)sizeof(float));                                          \
-    if (e != hipSuccess) return e;
-    SETG(64, 64, 5) SETG(128, 64, 3) SETG(64, 128, 3)
-#undef SETG
     if ((e = setup_stream<64, 64, 1, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<64, 32, 2, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
@@ -1040,14 +619,9 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
         return hipErrorInvalidValue;
     // range of the multiply-high divisions in the kernel (x / d exact while x * d < 2^32)
     if ((long long)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1ll << 32) || a.M >= (1 << 24)) return hipErrorInvalidValue;
-    static const bool stream = !(getenv("VNECT_STREAM") && atoi(getenv("VNECT_STREAM")) == 0);  // A/B against one tile per workgroup
     if (KG == 2 && BM == 64 && BN == 32) return launch_stream<64, 32, 2, 5>(a, st);
     if (KG == 4 && BM == 32 && BN == 32) return launch_stream<32, 32, 4, 4>(a, st);
-    if (KG != 1) return hipErrorInvalidValue;
-    if (BM == 64 && BN == 64 && stream) return launch_stream<64, 64, 1, 5>(a, st);
-    if (BM == 64 && BN == 64) return launch_g<64, 64, 5>(a, st);  // a 3-stage ring (3 workgroups per CU) was measured: no gain
-    if (BM == 128 && BN == 64) return launch_g<128, 64, 3>(a, st);
-    if (BM == 64 && BN == 128) return launch_g<64, 128, 3>(a, st);
+    if (KG == 1 && BM == 64 && BN == 64) return launch_stream<64, 64, 1, 5>(a, st);
     return hipErrorInvalidValue;
 }
 

@@ -386,12 +386,12 @@ void choose_tile(Layer& L, long long npix)
         else if (t32x32 > 128 && t32x32 <= 256 && L.a.cpt % 4 == 0) BM = 32, BN = 32, KG = 4;
         else ks = std::min(5, nch);  // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel
     }
-    const char* force = getenv("VNECT_FORCE_TILE");
+    const char* force = getenv("VNECT_FORCE_TILE");  // tuning: "BM,BN,KG,ks" for every layer that admits it
     if (force) {
-        int fBM = 0, fBN = 0, fks = 0;
-        if (sscanf(force, "%d,%d,%d", &fBM, &fBN, &fks) == 3 && fks >= 1 && fks <= 8 &&
-            ((fBM == 64 && fBN == 64) || (fBM == 128 && fBN == 64) || (fBM == 64 && fBN == 128)))
-            BM = fBM, BN = fBN, KG = 1, ks = std::min(fks, nch);
+        int fBM = 0, fBN = 0, fKG = 0, fks = 0;
+        if (sscanf(force, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) == 4 && fks >= 1 && fks <= 8 && L.a.cpt % std::max(fKG, 1) == 0 &&
+            ((fBM == 64 && fBN == 64 && fKG == 1) || (fBM == 64 && fBN == 32 && fKG == 2) || (fBM == 32 && fBN == 32 && fKG == 4)))
+            BM = fBM, BN = fBN, KG = fKG, ks = std::min(fks, nch / fKG);
     }
     L.BM = BM, L.BN = BN, L.KG = KG, L.a.ksplit = ks;
 }
