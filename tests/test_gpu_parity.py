@@ -122,6 +122,31 @@ def test_single_scale_and_paper_wiring(weights):
         assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4, paper
 
 
+@pytest.mark.parametrize("force", ["64,64,1,1", "64,32,2,1", "32,32,4,1", "64,64,1,5", "64,32,2,2", "32,32,4,3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_every_tile_shape_on_every_layer(weights, oracle_net, monkeypatch, force, prec):
+    """The launch plan picks a tile shape per layer (64x64, 64x32 x 2 K groups, 32x32 x 4 K groups, 5-way split-K); here
+    every shape is FORCED onto every layer that admits it (VNECT_FORCE_TILE = BM,BN,KG,ks), so each kernel variant --
+    including K groups combined with cross-workgroup slabs -- sees 1x1, 3x3, strided, transposed and 7x7 layers, S = 2."""
+    import oracle
+    from tests import helpers
+    scales = [1.0, 0.7]
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77, smooth=True), scales)
+    ref = oracle_net.forward(batch)
+    monkeypatch.setenv("VNECT_FORCE_TILE", force)
+    h = _handle(scales, weights, precision=_native().BF16 if prec == "bf16" else _native().FP32)
+    shapes = {(L["tile_m"], L["tile_n"], L["split_k"]) for L in h.layers() if L["M"]}
+    out = h.forward(batch)
+    again = h.forward(batch)
+    h.close()
+    bm, bn, kg, ks = (int(x) for x in force.split(","))
+    assert (bm, bn) in {(a, b) for a, b, _ in shapes}, shapes  # the forced shape is really in the plan
+    err = float(np.abs(out - ref).max() / np.abs(ref).max())
+    print(force, prec, "rel err %.3g" % err, sorted(shapes))
+    assert err <= (1e-4 if prec == "fp32" else 3e-2)
+    assert np.array_equal(out, again)  # K-group and slab sums run in a fixed order
+
+
 # ------------------------------------------------------------------------------------------ pre-processing
 @pytest.mark.parametrize("shape,smooth", [((368, 368), False), ((538, 368), True), ((300, 500), True),
                                           ((720, 1280), True), ((97, 61), False), ((368, 367), False)])

@@ -71,6 +71,8 @@ struct vnect_handle {
     size_t ws_floats = 0;
     float* zeros = nullptr;
     std::vector<void*> dev_allocs;
+    char* param_cur = nullptr;     // bump allocator over large blocks for packed weights / biases (param_alloc)
+    size_t param_left = 0;
     bool keep_activations = true;  // one private buffer per layer output (vnect_read_activation needs it); false = arena
     size_t arena_bytes = 0;
     // pre/post
@@ -140,10 +142,29 @@ int dev_alloc(vnect_handle* h, T** p, size_t count)
     return VNECT_OK;
 }
 
+// Parameters (packed weights, biases, BN vectors) are carved out of a few large blocks instead of ~150 separate
+// allocations: contiguous, 256-byte aligned, and mapped with large page fragments, so a layer's first touch of its
+// weights does not start with a page-table walk per 4 KiB.
+template <typename T>
+int param_alloc(vnect_handle* h, T** p, size_t count)
+{
+    const size_t need = (std::max<size_t>(count * sizeof(T), 16) + 255) & ~(size_t)255;
+    if (h->param_left < need) {
+        const size_t block = std::max<size_t>(need, (size_t)32 << 20);
+        char* q = nullptr;
+        int rc = dev_alloc(h, &q, block);
+        if (rc) return rc;
+        h->param_cur = q, h->param_left = block;
+    }
+    *p = (T*)h->param_cur;
+    h->param_cur += need, h->param_left -= need;
+    return VNECT_OK;
+}
+
 template <typename T>
 int upload(vnect_handle* h, T** dst, const std::vector<T>& v)
 {
-    int rc = dev_alloc(h, dst, v.size());
+    int rc = param_alloc(h, dst, v.size());
     if (rc) return rc;
     HIPCK(h, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return VNECT_OK;
