@@ -396,16 +396,16 @@ void choose_tile(Layer& L, long long npix)
     int BM = 64, BN = 64, KG = 1, ks = 1;
     const long long mt = (L.a.M + 63) / 64, nreal = L.Nreal;
     const long long tiles = mt * (round_up((int)nreal, 64) / 64) * L.a.nphase;
-    if (L.a.bf16) {  // bf16 loops are 2-3x shorter: the extra reduce launch only pays for the smallest, deepest layer
-        if (tiles <= 64 && kel >= 2048) ks = std::min(5, nch);
-    } else if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
+    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
         // Too few 64x64 tiles for 256 CUs and a long K: split K.  Inside the workgroup where that alone fills the chip
         // (one workgroup per CU, four K-parallel or M/N-parallel accumulators: no slabs, no reduce launch) ...
         const long long t64x32 = mt * (round_up((int)nreal, 32) / 32) * L.a.nphase;
         const long long t32x32 = ((L.a.M + 31) / 32) * (round_up((int)nreal, 32) / 32) * L.a.nphase;
         if (t64x32 > 128 && t64x32 <= 256 && L.a.cpt % 2 == 0) BM = 64, BN = 32, KG = 2;
         else if (t32x32 > 128 && t32x32 <= 256 && L.a.cpt % 4 == 0) BM = 32, BN = 32, KG = 4;
-        else ks = std::min(5, nch);  // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel
+        // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel (bf16 loops are 2-3x shorter: there the extra
+        // launch only pays for the smallest, deepest layers)
+        else if (!L.a.bf16 || (tiles <= 64 && kel >= 2048)) ks = std::min(5, nch);
     }
     const char* force = getenv("VNECT_FORCE_TILE");  // tuning: "BM,BN,KG,ks" for every layer that admits it
     if (force) {
