@@ -385,13 +385,15 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         // bias and shortcut of this tile: requested now so the epilogue never waits for them.  (Straight-line code
         // here and in the epilogue runs once per tile on a cold instruction cache -- ~35 cycles per instruction
         // measured -- so both are written for instruction count: scalar row bases stepped by additions, one lane offset.)
-        float bias = 0.f, sc = 1.f, sh = 0.f, rs[16];
+        float bias = 0.f, sc = 1.f, sh = 0.f;
+        unsigned rsw[16];  // shortcut values as loaded (fp32 bits, or a zero-extended bf16): converting a bf16 here would make
+                           // the compiler wait for the loads BEFORE the K loop (measured: 15 us per 92x92 shortcut layer)
         if (fused && kg == 0) {
             bias = ((cgfloat*)c.bias)[n];
             if (c.scale) sc = ((cgfloat*)c.scale)[n], sh = ((cgfloat*)c.shift)[n];
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) rs[r] = 0.f;
+        for (int r = 0; r < 16; r++) rsw[r] = 0u;
         if (resid && kg == 0) {
             // shortcut layers (os == 1).  Row r of the C layout is a UNIFORM distance from the lane's first row, so the
             // 16 requests share one 32-bit lane offset and differ in a scalar base: no address registers, no branches
@@ -399,13 +401,15 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             // (runtime.cpp), columns past Nvalid re-read column 0; both are masked at the store.
             const unsigned off = (unsigned)(mb * c.ldr + (n < c.Nvalid ? n : 0));
             if constexpr (BF) {
-                cgbf16* rp = (cgbf16*)resid;
+                typedef __attribute__((address_space(1))) const unsigned short cgu16;
+                cgu16* rp = (cgu16*)resid;
 #pragma unroll
-                for (int r = 0; r < 16; r++) rs[r] = (float)rp[off], rp += ((r & 3) == 3 ? 5 : 1) * c.ldr;
+                for (int r = 0; r < 16; r++) rsw[r] = rp[off], rp += ((r & 3) == 3 ? 5 : 1) * c.ldr;
             } else {
-                cgfloat* rp = resid;
+                typedef __attribute__((address_space(1))) const unsigned cgu32;
+                cgu32* rp = (cgu32*)resid;
 #pragma unroll
-                for (int r = 0; r < 16; r++) rs[r] = rp[off], rp += ((r & 3) == 3 ? 5 : 1) * c.ldr;
+                for (int r = 0; r < 16; r++) rsw[r] = rp[off], rp += ((r & 3) == 3 ? 5 : 1) * c.ldr;
             }
         }
 #pragma unroll
@@ -447,9 +451,12 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         // the values passed through it: otherwise the compiler re-waits (vmcnt(0)) for those loads before every use,
         // i.e. after every store below, and the 16 stores complete one by one (measured: 2.5-4.8 us per epilogue).
         asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(bias), "+v"(sc), "+v"(sh), "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]),
-                       "+v"(rs[6]), "+v"(rs[7]), "+v"(rs[8]), "+v"(rs[9]), "+v"(rs[10]), "+v"(rs[11]), "+v"(rs[12]), "+v"(rs[13]),
-                       "+v"(rs[14]), "+v"(rs[15]));
+                     : "+v"(bias), "+v"(sc), "+v"(sh), "+v"(rsw[0]), "+v"(rsw[1]), "+v"(rsw[2]), "+v"(rsw[3]), "+v"(rsw[4]), "+v"(rsw[5]),
+                       "+v"(rsw[6]), "+v"(rsw[7]), "+v"(rsw[8]), "+v"(rsw[9]), "+v"(rsw[10]), "+v"(rsw[11]), "+v"(rsw[12]), "+v"(rsw[13]),
+                       "+v"(rsw[14]), "+v"(rsw[15]));
+        float rs[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) rs[r] = __builtin_bit_cast(float, BF ? rsw[r] << 16 : rsw[r]);
         const int py = it.phase >> 1, px = it.phase & 1;
         const bool second = fused && c.out2 != nullptr && it.n0 >= c.split_n;  // two layers sharing one input run as one GEMM: columns [0, split_n) -> out, the rest -> out2 (split_n is a multiple of the tile width)
         gfloat* outp = (gfloat*)(!fused ? c.ws + (long long)it.ks * c.slab_pix * c.Npad : (second ? c.out2 : c.out));
