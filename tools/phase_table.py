@@ -33,6 +33,8 @@ for f in range(N):
         t0, t1 = st[0], max(st[1:9])
         r = [(t1 - t0), (t0 - prev_end) if prev_end else 0, st[10] - st[9], st[11] - st[10], st[12] - st[11], st[13] - st[12],
              st[15] - t0, st[9] - t0, st[16] / 23.0, st[17] / 23.0, st[18] / 23.0, st[19] / 23.0]
+        if f == N - 1 and os.environ.get('PT_PROD'):
+            print(l['name'][:24], 'producer wave 0 from workgroup start: args pinned %.2f, first item decoded %.2f, ring requested %.2f, chunk 0 landed %.2f us' % tuple((st[k] - st[9]) / 100.0 for k in (22, 23, 14, 11)))
         if f == N - 1 and os.environ.get('PT_SETUP'):
             print(l['name'][:24], 'from first chunk landed: K loop of item 0 %.2f, +epilogue issued %.2f, all items %.2f, stores drained %.2f' % tuple((st[k] - st[11]) / 100.0 for k in (20, 21, 12, 13)))
         rows.setdefault(i, []).append(r)

@@ -214,9 +214,18 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                     const int iy = oy * p.stride + (pix && BF ? unit >> 2 : 0);
                     const int ix = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
                     a_vo[i] = (unsigned)(((s * p.H + iy) * p.W + ix) * p.Cs * ESZ + (pix ? 0 : unit * 16));
-                    for (int t2 = 0; t2 < h.ntaps; t2++) {  // bit t2: tap t2 reads inside the image
-                        const int y = iy + tap_dy(tb + t2), x = ix + tap_dx(tb + t2);
-                        a_mask[i] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
+                    // bit t2: tap t2 reads inside the image.  1x1 and 3x3 (pad 1) grids in closed form; any other tap
+                    // table (7x7 rows of conv1, the transposed conv's phases) by walking it
+                    if (a.tapgrid == 1) {
+                        a_mask[i] = 1u;
+                    } else if (a.tapgrid == 3) {
+                        const unsigned vx = (ix >= 1 ? 1u : 0u) | 2u | (ix + 1 < p.W ? 4u : 0u);
+                        a_mask[i] = (iy >= 1 ? vx : 0u) | (vx << 3) | (iy + 1 < p.H ? vx << 6 : 0u);
+                    } else {
+                        for (int t2 = 0; t2 < h.ntaps; t2++) {
+                            const int y = iy + tap_dy(tb + t2), x = ix + tap_dx(tb + t2);
+                            a_mask[i] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
+                        }
                     }
                 }
             }
@@ -257,33 +266,41 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 default: wait_vm<0>(); break;
             }
         };
+        const bool pst = P2 && threadIdx.x == 256 && blockIdx.x == 0;
+        if (pst) prof[22] = __builtin_amdgcn_s_memrealtime();  // producer wave 0: arguments pinned, about to decode the first item
         begin_item(0);
-#pragma unroll
-        for (int q = 0; q < NS - 1; q++)
-            if (q < G) issue(q);
-        wait_landed(G - 1 < NS - 2 ? G - 1 : NS - 2);
+        if (pst) prof[23] = __builtin_amdgcn_s_memrealtime();  // first item decoded
+        // The consumers can start as soon as chunk 0 has landed, so only chunks 0 and 1 are requested before the first
+        // barrier; the rest of the ring is filled behind it, two chunks per iteration until NS-1 are in flight.  (Filling
+        // the whole ring first kept the matrix pipes waiting for 0.6-1.5 us of producer bookkeeping per launch.)
+        int nis = 0, istage = 0, g = 0;  // chunks issued; stage of the next chunk to issue
+        auto put = [&]() __attribute__((always_inline)) {
+            issue(istage);
+            istage = istage + 1 == NS ? 0 : istage + 1, nis++;
+        };
+        put();
+        if (G > 1) put();
+        if (pst) prof[14] = __builtin_amdgcn_s_memrealtime();  // chunks 0 and 1 requested
+        wait_landed(nis - 1);
         __builtin_amdgcn_s_barrier();  // chunk 0 visible
-        int stage = 0, g = 0;
+        if (G > 2) put();
         const bool pacct = P2 && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
         long long pw = 0, pb = 0, pi = 0;
         // one barrier per chunk, also after the last one (keeps the consumer loop branch-free).  Steady state: chunk g+1
         // complete in LDS, chunks g+2 .. g+NS-2 still in flight, chunk g+NS-1 issued behind the barrier that retires
         // stage g-1.
-        for (; g + NS - 1 < G; g++) {
+        for (; g < G; g++) {
             const long long q0 = P2 ? __builtin_amdgcn_s_memtime() : 0;
-            wait_vm<(NS - 3) * NLD>();
+            const int young = nis - g - 2;  // chunks allowed to be still in flight once chunk g+1 has landed
+            if (young == NS - 3) wait_vm<(NS - 3) * NLD>();
+            else wait_landed(young > 0 ? young : 0);
             const long long q1 = P2 ? __builtin_amdgcn_s_memtime() : 0;
             __builtin_amdgcn_s_barrier();  // consumers are past chunk g-1: its stage may be refilled
             const long long q2 = P2 ? __builtin_amdgcn_s_memtime() : 0;
-            issue(stage == 0 ? NS - 1 : stage - 1);
+            const int target = G < g + NS ? G : g + NS;
+            while (nis < target) put();
             const long long q3 = P2 ? __builtin_amdgcn_s_memtime() : 0;
             pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
-            stage = stage + 1 == NS ? 0 : stage + 1;
-        }
-        for (; g < G; g++) {  // drain: nothing left to issue
-            const int young = G - 2 - g;
-            wait_landed(young < NS - 3 ? young : NS - 3);
-            __builtin_amdgcn_s_barrier();
         }
         if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
         return;

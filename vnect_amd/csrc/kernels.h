@@ -54,6 +54,7 @@ struct ConvArgs {
     // the same tap table as 4-bit fields (value + 8, entry [phase*ntaps + tap] at bits 4*entry): the streaming kernel's
     // producers decode dy / dx with scalar shifts instead of one dependent scalar load per tap
     unsigned long long dy_pack, dx_pack;
+    int tapgrid;  // 1: single tap (0,0); 3: the 3x3 grid with pad 1 (validity masks in closed form); 0: walk the table
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

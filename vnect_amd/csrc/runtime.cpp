@@ -790,6 +790,13 @@ int finalize_impl(vnect_handle* h)
             int lo = 0;
             for (int t = 0; t < nt; t++) lo = std::min(lo, (a.dy[t] * a.W + a.dx[t]) * a.Cs * esz);
             a.tap_bias = -lo;
+            a.tapgrid = 0;
+            if (a.nphase == 1 && a.ntaps == 1 && a.dy[0] == 0 && a.dx[0] == 0 && !a.pixmode) a.tapgrid = 1;
+            if (a.nphase == 1 && a.ntaps == 9 && !a.pixmode) {
+                bool ok = true;
+                for (int t = 0; t < 9; t++) ok = ok && a.dy[t] == t / 3 - 1 && a.dx[t] == t % 3 - 1;
+                if (ok) a.tapgrid = 3;
+            }
             a.dy_pack = a.dx_pack = 0;
             for (int t = 0; t < nt; t++) {
                 if (a.dy[t] < -8 || a.dy[t] > 7 || a.dx[t] < -8 || a.dx[t] > 7) {
