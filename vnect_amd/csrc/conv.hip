@@ -133,7 +133,9 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         const int cnt = qd + (xcd < rm ? 1 : 0);
         const int nwx = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
         it_first = lo + l, it_stride = nwx;
-        my_n = __builtin_amdgcn_readfirstlane(l < cnt ? (cnt - l + nwx - 1) / nwx : 0);
+        // one item per workgroup (grid == items, most layers): skip the integer division (~35 cold instructions)
+        if (h.items == nwg) my_n = 1;
+        else my_n = __builtin_amdgcn_readfirstlane(l < cnt ? (cnt - l + nwx - 1) / nwx : 0);
     }
     if (my_n == 0) return;  // whole workgroup: no barrier has been issued yet
     const int nch = h.ntaps * h.cpt;  // K steps per tile (the launcher passes cpt in steps of KG chunks)
