@@ -129,6 +129,34 @@ def main():
     pipelined = args.steps / (time.perf_counter() - p0)
     t += 1 + args.steps / 30 + 1
 
+    # two independent video streams sharing this GPU (two handles, two host threads): what the idle CUs between the
+    # launches of one synchronous stream are worth.  Reported beside the headline, never as `value`.
+    two_streams = None
+    if not args.pyramid and rank == 0:
+        import threading
+        h2 = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec)
+        h2.set_weights(weights)
+        h2.finalize()
+        for k in range(nslots):
+            h2.upload_frame(k, helpers.synth_frame(stream_seed(rank + 1000, k)))
+
+        def drive(hh, base, n):
+            for i in range(n):
+                hh.infer_resident(i % nslots, base + i / 30, base + i / 30 + 1e-3)
+
+        drive(h2, t + 50, args.warmup)
+        ths = [threading.Thread(target=drive, args=(hh, t + 100, args.steps)) for hh in (h, h2)]
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize()
+        two_streams = 2 * args.steps / (time.perf_counter() - q0)
+        h2.close()
+        t += 100 + args.steps / 30 + 1
+
     out = None
     tim = None
     if rank == 0 or args.pyramid:  # pyramid: every inference is collective, so every rank must take part
@@ -172,6 +200,7 @@ def main():
                        "hip_graph": not args.no_graph and not args.pyramid, "sync_per_frame": True,
                        "parallelism": "pyramid: 1 scale per GPU + RCCL all-gather" if args.pyramid else "stream replicas"},
             "pipelined_frames_per_s_per_gpu": round(pipelined, 2),
+            "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
             "roofline": dict(
                          # fp32: the conv stack is MFMA-bound.  bf16: 16x the MFMA rate makes the
                          # same stack memory/latency-bound -- priced against HBM with its algorithmic bytes (bf16 weights

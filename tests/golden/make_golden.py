@@ -11,6 +11,7 @@ travels.  Nothing here copies reference source: the reference modules are import
                       cv2.resize is the oracle's restatement of OpenCV bilinear
   F4 net_samples.npz  oracle network on seeded weights/frame: sampled activations per stage,
                       cross-checked here against the independent torch-f64 restatement
+  F6 angles.npz       src/joints2angles.py Joints2Angles (static formula + filtered __call__ with a scripted clock)
   test_pic.jpg        the reference's own data file pic/test_pic.jpg (data, 368 wide x 538 tall)
 """
 import contextlib
@@ -187,8 +188,25 @@ def gen_net_samples():
     np.savez(os.path.join(HERE, "net_samples.npz"), **data)
 
 
+# --------------------------------------------------------------------------- F6
+def gen_angles():
+    import joints2angles as ref
+    n = 24
+    u = uniform01(606, n * 63 + n).astype(np.float64)
+    joints = ((u[:n * 63] - 0.5) * 1200.0).reshape(n, 21, 3).astype(np.float32)  # mm, like extract_3d_joints' output
+    ts = 1.7e9 + np.cumsum(1 / 30 * (0.5 + u[n * 63:]))
+    static = np.array([ref.Joints2Angles.joints2angles(j) for j in joints])
+    with contextlib.redirect_stdout(io.StringIO()):
+        obj = ref.Joints2Angles(filter=True)
+        clock = iter(np.repeat(ts, 8))          # __call__ reads time.time() once per angle (joints2angles.py:50)
+        ref.time.time = lambda: float(next(clock))
+        filtered = np.array([obj(j) for j in joints])
+    np.savez(os.path.join(HERE, "angles.npz"), joints=joints, ts=ts, static=static, filtered=filtered)
+
+
 if __name__ == "__main__":
     install_stubs()
+    gen_angles()
     gen_oneeuro()
     gen_readoff()
     gen_glue()

@@ -97,3 +97,18 @@ def test_net_samples_pinned(weights):
             assert np.array_equal(a, g["val_" + n]), n
             assert np.abs(a - g["f64_" + n]).max() <= 2e-5 * max(np.abs(net.activation(n)).max(), 1e-6), n
     assert out.astype(np.float64).sum() == g["out_sum"]
+
+
+def test_joints2angles_matches_reference_recording():
+    """vnect_amd.angles.Joints2Angles vs values recorded from src/joints2angles.py (angles.npz):
+    the static formula and the OneEuro-filtered __call__ with the recorded clock, bit for bit."""
+    from vnect_amd.angles import Joints2Angles
+    g = np.load(os.path.join(G, "angles.npz"))
+    static = np.array([Joints2Angles.joints2angles(j) for j in g["joints"]])
+    assert static.dtype == g["static"].dtype and np.array_equal(static, g["static"])
+    obj = Joints2Angles(filter=True)
+    filtered = np.array([obj(j, timestamp=float(t)) for j, t in zip(g["joints"], g["ts"])])
+    assert np.array_equal(filtered, g["filtered"])
+    assert np.array_equal(filtered[0], static[0])  # first call of a OneEuro filter is the identity
+    plain = Joints2Angles(filter=False)
+    assert np.array_equal(np.array(plain(g["joints"][3])), static[3])
