@@ -32,6 +32,11 @@ def cpu_baseline(weights, budget_s):
     from tests import helpers
     est = oracle.OracleEstimator(weights=weights, scales=SCALES)
     frames = [helpers.synth_frame(1234 + k) for k in range(4)]
+    # The port's blocked SGEMM stops scaling at ~16 threads on the 23x23 / 46x46 layers (measured on the GPU box:
+    # 8 / 16 / 32 / 64 / 128 threads -> 3.6 / 4.0 / 3.7 / 2.9 / 1.6 frames/s), so it runs on at most 16 and says so.
+    L = oracle.lib()
+    L.vo_set_threads.argtypes = [__import__("ctypes").c_int]
+    L.vo_set_threads(min(16, len(os.sched_getaffinity(0))))
     est(frames[0], 1.0, 1.0)  # warm-up (page-in, thread pool)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -42,7 +47,8 @@ def cpu_baseline(weights, budget_s):
             break
     cores = oracle.lib().vo_sgemm_threads()
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same workload in %.1f s (C/OpenMP fp32 oracle, AVX2/AVX-512 SGEMM)" % (n, dt)}
+            "sample": "%d frames of the same workload in %.1f s (C/OpenMP fp32 oracle, AVX2/AVX-512 SGEMM, threads capped at 16 "
+                      "of %d host cores: more are slower)" % (n, dt, len(os.sched_getaffinity(0)))}
 
 
 def main():

@@ -171,6 +171,7 @@ void vo_sgemm(int M, int N, int K, const float* A, int lda, const float* B, int 
 }
 
 int vo_sgemm_threads(void) { return omp_get_max_threads(); }
+void vo_set_threads(int n) { if (n >= 1) omp_set_num_threads(n); }
 
 /* ------------------------------------------------------------------------------------ */
 /* network                                                                              */

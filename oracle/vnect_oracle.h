@@ -48,6 +48,7 @@ int vo_net_forward(vo_net*, const float* batch, int S, float* out);
 const float* vo_net_activation(vo_net*, const char* name, int* shape);
 const char* vo_net_error(vo_net*);
 int vo_sgemm_threads(void);
+void vo_set_threads(int n);  /* OpenMP threads of the GEMM and element-wise loops (bench.py's cpu_baseline picks the fastest count) */
 /* plain C = A*B helper exported for unit tests */
 void vo_sgemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc);
 
