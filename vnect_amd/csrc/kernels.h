@@ -88,14 +88,18 @@ struct ResizeTab {  // 8-bit bilinear tables for one destination axis pair (Open
     int16_t sy0[BOX], sy1[BOX], b0[BOX], b1[BOX];
 };
 
-struct FrameParams {  // per frame, written by the host into pinned memory and copied in-stream
-    double t2d, t3d, scaler;
+struct FrameParams {  // crop GEOMETRY: depends on the crop size (H, W) only, so it is uploaded when that changes -- never
+                      // for a stream of equally sized crops
+    double scaler;
     int offx, offy;
     int H, W;
-    long long row_stride;
-    const uint8_t* frame;  // device pointer
-    int pad_;
     ResizeTab sq;          // squarify resize (utils.img_scale_squarify)
+};
+struct FrameDyn {     // what does change every frame: passed to the two kernels that need it BY VALUE (kernel arguments),
+                      // so a frame costs no host-to-device copy
+    double t2d, t3d;
+    const uint8_t* frame;  // device pointer
+    long long row_stride;
 };
 
 struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.img_scale_padding)
@@ -106,7 +110,7 @@ struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.
     float lut[256]; // (float)v / 255 - 0.4 in float32
 };
 
-hipError_t launch_pyramid(const FrameParams* fp, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
+hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
 // ---- post-processing ------------------------------------------------------------------
 struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale
@@ -149,7 +153,8 @@ struct JointsOut {
 
 hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, double* hm, ArgPartial* part,
                          hipStream_t st);
+// out may be (device-mapped) pinned HOST memory: the kernel's 21x2 + 21x3 results then need no device-to-host copy
 hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
-                         const FrameParams* fp, int nep50, JointsOut* out, hipStream_t st);
+                         const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st);
 
 }  // namespace vnect

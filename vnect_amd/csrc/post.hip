@@ -45,14 +45,14 @@ __device__ __forceinline__ void sample_u8x3(Px px, const ResizeTab& t, int dy, i
 
 // utils.img_scale_squarify + img_padding (utils.py:82-120): pixel (y, x) of the 368x368 canvas, computed from the
 // frame on demand (the canvas itself is never materialised)
-__device__ __forceinline__ void square_pixel(const FrameParams* __restrict__ fp, int y, int x, int v[3])
+__device__ __forceinline__ void square_pixel(const FrameParams* __restrict__ fp, const FrameDyn& dyn, int y, int x, int v[3])
 {
     const ResizeTab& t = fp->sq;
     const int dy = y - fp->offy, dx = x - fp->offx;
     v[0] = v[1] = v[2] = 0;
     if (dy >= 0 && dy < t.dh && dx >= 0 && dx < t.dw) {
-        const uint8_t* frame = fp->frame;
-        const long long pitch = fp->row_stride;
+        const uint8_t* frame = dyn.frame;
+        const long long pitch = dyn.row_stride;
         auto fpx = [&](int r, int c, int* o) {
             const uint8_t* p = frame + (long long)r * pitch + c * 3;
             o[0] = p[0], o[1] = p[1], o[2] = p[2];
@@ -65,7 +65,7 @@ __device__ __forceinline__ void square_pixel(const FrameParams* __restrict__ fp,
 // gen_input_batch in one kernel (estimator.py:70-81): squarify, utils.img_scale_padding per scale (each stage rounds
 // to uint8 exactly like the two cv2.resize calls of the reference) and `/255 - 0.4` -> (S,368,368,4), 4th channel 0
 template <typename T>
-__global__ void pyramid_kernel(const FrameParams* __restrict__ fp, const ScaleTabs* __restrict__ tabs,
+__global__ void pyramid_kernel(const FrameParams* __restrict__ fp, const FrameDyn dyn, const ScaleTabs* __restrict__ tabs,
                                T* __restrict__ batch4, int scale_base)
 {
     typedef T tx4 __attribute__((ext_vector_type(4)));
@@ -74,12 +74,12 @@ __global__ void pyramid_kernel(const FrameParams* __restrict__ fp, const ScaleTa
     if (x >= BOX) return;
     int v[3] = {0, 0, 0};
     if (!tabs->scaled[s]) {
-        square_pixel(fp, y, x, v);
+        square_pixel(fp, dyn, y, x, v);
     } else {
         const ResizeTab& t = tabs->t[s];
         const int dy = y - tabs->pad[s], dx = x - tabs->pad[s];
         if (dy >= 0 && dy < t.dh && dx >= 0 && dx < t.dw) {
-            auto spx = [&](int r, int c, int* o) { square_pixel(fp, r, c, o); };
+            auto spx = [&](int r, int c, int* o) { square_pixel(fp, dyn, r, c, o); };
             if (t.copy) spx(dy, dx, v);
             else sample_u8x3(spx, t, dy, dx, v);
         }
@@ -88,11 +88,11 @@ __global__ void pyramid_kernel(const FrameParams* __restrict__ fp, const ScaleTa
     *(tx4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4) = __builtin_convertvector(o, tx4);
 }
 
-hipError_t launch_pyramid(const FrameParams* fp, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st)
+hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st)
 {
     dim3 g((BOX + 127) / 128, BOX, S);
-    if (bf16) hipLaunchKernelGGL(pyramid_kernel<__bf16>, g, dim3(128), 0, st, fp, tabs, (__bf16*)batch4, scale_base);
-    else hipLaunchKernelGGL(pyramid_kernel<float>, g, dim3(128), 0, st, fp, tabs, (float*)batch4, scale_base);
+    if (bf16) hipLaunchKernelGGL(pyramid_kernel<__bf16>, g, dim3(128), 0, st, fp, dyn, tabs, (__bf16*)batch4, scale_base);
+    else hipLaunchKernelGGL(pyramid_kernel<float>, g, dim3(128), 0, st, fp, dyn, tabs, (float*)batch4, scale_base);
     return hipGetLastError();
 }
 
@@ -310,7 +310,7 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
 // (x/y/z maps merged on demand) + root subtraction + 63 3-D filters, then the un-mapping.
 __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
                                                      const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
-                                                     const FrameParams* __restrict__ fp, int nep50,
+                                                     const FrameParams* __restrict__ fp, const FrameDyn dyn, int nep50,
                                                      JointsOut* __restrict__ out)
 {
     __shared__ double c2[NJ * 2];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
     const int j3 = t < NJ * 3 ? t / 3 : 0, k3 = t < NJ * 3 ? t - 3 * j3 : 0;
     Filt f2 = fb->f2[j2][k2];
     Filt f3 = fb->f3[j3][k3];
-    const double t2d = fp->t2d, t3d = fp->t3d, scaler = fp->scaler;
+    const double t2d = dyn.t2d, t3d = dyn.t3d, scaler = fp->scaler;
     const double off = k2 == 0 ? (double)fp->offy : (double)fp->offx;
     double pv[ARG_SLABS];
     int pi[ARG_SLABS];
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
     if (t == 0) out->status = 0;
 }
 hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
-                         const FrameParams* fp, int nep50, JointsOut* out, hipStream_t st)
+                         const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(joints_kernel, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, nep50, out);
+    hipLaunchKernelGGL(joints_kernel, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, dyn, nep50, out);
     return hipGetLastError();
 }
 

@@ -79,8 +79,11 @@ struct vnect_handle {
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; };
     std::vector<SlotInfo> slots;
-    FrameParams* d_fp = nullptr;
-    FrameParams* h_fp[RING] = {};  // pinned
+    FrameParams* d_fp = nullptr;   // crop geometry on the device; re-uploaded only when it differs from fp_dev
+    FrameParams* h_fp[RING] = {};  // pinned staging for those uploads
+    FrameParams fp_dev{};          // what d_fp holds
+    bool fp_dev_valid = false;
+    int fp_ring = 0;
     ScaleTabs* d_stabs = nullptr;
     MergeTabs* d_mtabs = nullptr;
     UpTab* d_up = nullptr;
@@ -88,7 +91,8 @@ struct vnect_handle {
     double* d_hm = nullptr;  // merged heat-maps, joint-major (21,46,46) f64
     FilterBank* d_fb = nullptr;
     JointsOut* d_out = nullptr;
-    JointsOut* h_out[RING] = {};  // pinned
+    JointsOut* h_out[RING] = {};   // pinned, device-mapped: joints_kernel writes a frame's results straight into its ring slot
+    JointsOut* h_out_dev[RING] = {};  // the same slots as the device addresses them
     hipEvent_t done[RING] = {};
     unsigned long long seq_submit = 0, seq_collect = 0;
     bool have2 = false, have3 = false;
@@ -840,18 +844,38 @@ int run_network(vnect_handle* h, bool timed)
     return VNECT_OK;
 }
 
-int run_pre(vnect_handle* h)
+// Crop geometry -> d_fp, only if it differs from what the device holds (a stream of equally sized crops never uploads).
+// In-stream, so frames still in flight keep the geometry they were launched with.
+int sync_geometry(vnect_handle* h, const FrameParams& fp)
 {
-    HIPCK(h, launch_pyramid(h->d_fp, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
+    if (h->fp_dev_valid && memcmp(&h->fp_dev, &fp, sizeof fp) == 0) return VNECT_OK;
+    const int r = h->fp_ring = (h->fp_ring + 1) % RING;  // a staging slot of its own: earlier copies may still be queued
+    *h->h_fp[r] = fp;
+    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[r], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
+    h->fp_dev = fp, h->fp_dev_valid = true;
+    return VNECT_OK;
+}
+
+int run_pre(vnect_handle* h, const FrameDyn& dyn)
+{
+    HIPCK(h, launch_pyramid(h->d_fp, dyn, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
                             h->sharded ? h->cfg.pyramid_rank : 0, h->bf16, h->st));
     return VNECT_OK;
 }
 
-int run_post(vnect_handle* h)
+// multi-scale merge + arg-max (graph-capturable: no per-frame arguments)
+int run_argmax(vnect_handle* h)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
     HIPCK(h, launch_argmax(maps, h->d_mtabs, h->S, h->d_up, h->d_hm, h->d_part, h->st));
-    HIPCK(h, launch_joints(h->d_part, maps, h->d_mtabs, h->S, h->d_fb, h->d_fp, h->cfg.numpy_promotion, h->d_out, h->st));
+    return VNECT_OK;
+}
+
+// filters + read-off; results go straight to `out` (a device-mapped pinned host slot, or d_out)
+int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
+{
+    const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
+    HIPCK(h, launch_joints(h->d_part, maps, h->d_mtabs, h->S, h->d_fb, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
     return VNECT_OK;
 }
 
@@ -922,16 +946,17 @@ int all_gather_maps(vnect_handle* h)
     return VNECT_OK;
 }
 
+// The part of a frame without per-frame arguments (what the hipGraph holds): conv stack, [all-gather], merge + arg-max.
+// The pyramid kernel before it and the joints kernel after it take the frame's arguments by value and are launched
+// around the graph.
 int run_frame_kernels(vnect_handle* h, bool timed)
 {
     const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
     if (timed) HIPCK(h, hipMemcpyAsync(h->d_prof, h->h_prof_init, pbytes, hipMemcpyHostToDevice, h->st));
-    int rc = run_pre(h);
-    if (rc) return rc;
-    rc = run_network(h, timed);
+    int rc = run_network(h, timed);
     if (rc) return rc;
     if (h->sharded && (rc = all_gather_maps(h))) return rc;
-    rc = run_post(h);
+    rc = run_argmax(h);
     if (rc) return rc;
     if (timed) HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
     return VNECT_OK;
@@ -975,25 +1000,24 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     rc = check_time(h, t2d, t3d);
     if (rc) return rc;
     const int ring = (int)(h->seq_submit % RING);
-    fp.t2d = t2d, fp.t3d = t3d;
-    fp.row_stride = si.stride;
-    fp.frame = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
-    *h->h_fp[ring] = fp;
-    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[ring], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
+    FrameDyn dyn;
+    dyn.t2d = t2d, dyn.t3d = t3d;
+    dyn.row_stride = si.stride;
+    dyn.frame = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
+    if ((rc = sync_geometry(h, fp))) return rc;
     const bool timed = h->profiling;
+    if (timed) HIPCK(h, hipEventRecord(h->ev[0], h->st));
+    if ((rc = run_pre(h, dyn))) return rc;
     if (h->gexec && !timed) {
         HIPCK(h, hipGraphLaunch(h->gexec, h->st));
     } else if (h->pgexec && timed) {
-        HIPCK(h, hipEventRecord(h->ev[0], h->st));
         HIPCK(h, hipGraphLaunch(h->pgexec, h->st));
-        HIPCK(h, hipEventRecord(h->ev[3], h->st));
     } else {
-        if (timed) HIPCK(h, hipEventRecord(h->ev[0], h->st));
         rc = run_frame_kernels(h, timed);
         if (rc) return rc;
-        if (timed) HIPCK(h, hipEventRecord(h->ev[3], h->st));
     }
-    HIPCK(h, hipMemcpyAsync(h->h_out[ring], h->d_out, sizeof(JointsOut), hipMemcpyDeviceToHost, h->st));
+    if ((rc = run_joints(h, dyn, h->h_out_dev[ring]))) return rc;  // writes the ring slot in pinned host memory
+    if (timed) HIPCK(h, hipEventRecord(h->ev[3], h->st));
     HIPCK(h, hipEventRecord(h->done[ring], h->st));
     h->seq_submit++;
     *ring_out = ring;
@@ -1004,7 +1028,12 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
 {
     if (h->seq_collect == h->seq_submit) return fail(h, VNECT_E_STATE, "nothing in flight");
     const int ring = (int)(h->seq_collect % RING);
-    HIPCK(h, hipEventSynchronize(h->done[ring]));
+    // the caller is about to consume the joints: poll (a frame is ~1 ms) before falling back to a blocking wait, whose
+    // wake-up alone costs tens of microseconds of idle GPU per frame
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 200000 && (q = hipEventQuery(h->done[ring])) == hipErrorNotReady; spin++) {}
+    if (q == hipErrorNotReady) q = hipEventSynchronize(h->done[ring]);
+    HIPCK(h, q);
     h->seq_collect++;
     if (j2) memcpy(j2, h->h_out[ring]->j2d, sizeof(double) * NJ * 2);
     if (j3) memcpy(j3, h->h_out[ring]->j3d, sizeof(float) * NJ * 3);
@@ -1100,7 +1129,8 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
     for (int i = 0; i < RING; i++) {
         HIPCK(h, hipHostMalloc((void**)&h->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
-        HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocDefault));
+        HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCK(h, hipHostGetDevicePointer((void**)&h->h_out_dev[i], h->h_out[i], 0));
         HIPCK(h, hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming));
     }
     for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
@@ -1221,10 +1251,10 @@ int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t 
     if (rc) return rc;
     FrameParams fp;
     if ((rc = squarify_params(h, H, W, &fp))) return rc;
-    fp.row_stride = h->slots[0].stride, fp.frame = h->frames;
-    *h->h_fp[0] = fp;
-    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[0], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
-    if ((rc = run_pre(h))) return rc;
+    FrameDyn dyn{};
+    dyn.row_stride = h->slots[0].stride, dyn.frame = h->frames;
+    if ((rc = sync_geometry(h, fp))) return rc;
+    if ((rc = run_pre(h, dyn))) return rc;
     if (batch_out) {
         const long long npix = (long long)h->Snet * BOX * BOX;
         HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->bf16, h->st));
@@ -1251,11 +1281,12 @@ int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d
     HIPCK(h, hipMemcpyAsync(dst, maps, (size_t)h->S * HM * HM * MAPC * sizeof(float), hipMemcpyHostToDevice, h->st));
     FrameParams fp;
     memset(&fp, 0, sizeof fp);
-    fp.t2d = t2d, fp.t3d = t3d, fp.scaler = scaler, fp.offx = offset_x, fp.offy = offset_y;
-    *h->h_fp[0] = fp;
-    HIPCK(h, hipMemcpyAsync(h->d_fp, h->h_fp[0], sizeof(FrameParams), hipMemcpyHostToDevice, h->st));
-    if ((rc = run_post(h))) return rc;
-    HIPCK(h, hipMemcpyAsync(h->h_out[0], h->d_out, sizeof(JointsOut), hipMemcpyDeviceToHost, h->st));
+    fp.scaler = scaler, fp.offx = offset_x, fp.offy = offset_y;
+    FrameDyn dyn{};
+    dyn.t2d = t2d, dyn.t3d = t3d;
+    if ((rc = sync_geometry(h, fp))) return rc;
+    if ((rc = run_argmax(h))) return rc;
+    if ((rc = run_joints(h, dyn, h->h_out_dev[0]))) return rc;
     HIPCK(h, hipStreamSynchronize(h->st));
     memcpy(j2, h->h_out[0]->j2d, sizeof(double) * NJ * 2);
     memcpy(j3, h->h_out[0]->j3d, sizeof(float) * NJ * 3);
