@@ -12,6 +12,9 @@ travels.  Nothing here copies reference source: the reference modules are import
   F4 net_samples.npz  oracle network on seeded weights/frame: sampled activations per stage,
                       cross-checked here against the independent torch-f64 restatement
   F6 angles.npz       src/joints2angles.py Joints2Angles (static formula + filtered __call__ with a scripted clock)
+  F7 caffe_shapes.json  the OUTPUT CELLS of materials/caffe_script.ipynb (the authors' pycaffe session): blob shape of
+                      every layer (cell 3) and shape of every parameter blob (cell 5) -- recorded data, the structural
+                      known answers of the network
   test_pic.jpg        the reference's own data file pic/test_pic.jpg (data, 368 wide x 538 tall)
 """
 import contextlib
@@ -204,8 +207,28 @@ def gen_angles():
     np.savez(os.path.join(HERE, "angles.npz"), joints=joints, ts=ts, static=static, filtered=filtered)
 
 
+# --------------------------------------------------------------------------- F7
+def gen_caffe_shapes():
+    import json
+    import re
+    nb = json.load(open(os.path.join(REF, "materials", "caffe_script.ipynb")))
+    outs = ["".join("".join(o.get("text", [])) for o in c.get("outputs", [])) for c in nb["cells"]]
+    blobs = {m.group(1): [int(x) for x in m.group(2).split(",")]
+             for m in re.finditer(r"The output shape of layer (\S+) is \(([\d, ]+)\)", outs[3])}
+    params, name = {}, None
+    for line in outs[5].splitlines():
+        if line.strip() and not line.startswith("\t"):
+            name = line.strip()
+            params[name] = []
+        elif line.strip():
+            params[name].append([int(x) for x in re.findall(r"\d+", line)])
+    assert len(blobs) > 100 and len(params) == 56 and sum(len(v) for v in params.values()) == 110
+    json.dump({"blobs": blobs, "params": params}, open(os.path.join(HERE, "caffe_shapes.json"), "w"), indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     install_stubs()
+    gen_caffe_shapes()
     gen_angles()
     gen_oneeuro()
     gen_readoff()

@@ -76,3 +76,51 @@ def test_batch_rows_independent(weights):
     both = net.forward(batch)
     one = net.forward(batch[1:2])
     assert np.array_equal(both[1:2], one)
+
+
+def test_shapes_match_the_authors_caffe_session(weights):
+    """Known answers recorded in the reference: materials/caffe_script.ipynb holds the OUTPUT of the authors' pycaffe
+    session -- the blob shape of every layer (cell 3) and the shape of every parameter blob (cell 5); both are committed
+    as data in tests/golden/caffe_shapes.json.  Every activation the oracle names must have the caffe blob's shape, and
+    the weight schema must be the caffe parameters after caffe2pkl's transposes (src/caffe2pkl.py:48,60-80)."""
+    import json
+    import os
+    from vnect_amd.weights import schema
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "caffe_shapes.json")))
+    blobs, params = g["blobs"], g["params"]
+    net = oracle.Oracle(weights, keep=True)
+    net.forward(_frame_batch(5))
+    checked = 0
+    for blob, (c, hh, ww) in blobs.items():
+        for name in (blob, blob + "_new"):  # caffe LAYERS res5a/5b carry a _new suffix that their blobs do not
+            try:
+                a = net.activation(name)
+            except Exception:
+                continue
+            assert a.shape == (1, hh, ww, c), (name, a.shape, (c, hh, ww))
+            checked += 1
+            break
+    assert checked >= 50, checked  # every activation the oracle names (54: convs, block outputs, deconvs, the 212-channel feature)
+    assert blobs["x_heatmap"] == [21, 46, 46] and net.forward(_frame_batch(5)).shape == (1, 46, 46, 4 * 21)
+    sch = dict(schema())
+    n_arrays = 0
+    for layer, shapes in params.items():
+        if layer == "bn5c_branch2a":        # caffe BatchNorm: mean, variance, scale factor (folded by caffe2pkl.py:74-75)
+            assert shapes == [[128], [128], [1]]
+            assert sch[layer + "/moving_mean"] == (128,) and sch[layer + "/moving_variance"] == (128,)
+            n_arrays += 2
+        elif layer == "scale5c_branch2a":   # caffe Scale: gamma, beta
+            assert shapes == [[128], [128]]
+            assert sch["bn5c_branch2a/gamma"] == (128,) and sch["bn5c_branch2a/beta"] == (128,)
+            n_arrays += 2
+        elif len(shapes) == 1:              # bias-free conv / deconv -> '<scope>/kernel'
+            o, i, kh, kw = shapes[0]
+            want = (kh, kw, i, o) if layer == "res5c_branch2c" else (kh, kw, i, o)
+            # caffe stores a Deconvolution as (Cin, Cout, kh, kw): the same (2,3,1,0) transpose yields (kh, kw, Cout, Cin)
+            assert sch[layer + "/kernel"] == want, (layer, sch[layer + "/kernel"], want)
+            n_arrays += 1
+        else:                               # conv with bias: (Cout, Cin, kh, kw) -> (kh, kw, Cin, Cout)
+            o, i, kh, kw = shapes[0]
+            assert sch[layer + "/weights"] == (kh, kw, i, o) and sch[layer + "/biases"] == tuple(shapes[1]), layer
+            n_arrays += 2
+    assert n_arrays == len(sch) == 109
