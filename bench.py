@@ -90,7 +90,8 @@ def main():
             sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
         h = _native.Handle(SCALES, device=local_rank, num_frame_slots=8, pyramid=(rank, world), precision=prec)
     else:
-        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec)
+        # lanes=2: the second lane only ever runs a frame submitted while another is in flight (the pipelined leg below)
+        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec, lanes=2)
     h.set_weights(weights)
     h.finalize()
     if args.pyramid:  # rank 0 makes the ncclUniqueId, torch.distributed carries it to the others
@@ -123,7 +124,8 @@ def main():
     elapsed = grp.max_over_ranks(elapsed)
     assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
 
-    # two-deep pipelined rate of the same stream (submit k+1 before collecting k), reported beside the serial one
+    # two-deep pipelined rate of the same stream (submit k+1 before collecting k; the frames overlap on two lanes, only the
+    # filter kernels stay ordered), reported beside the synchronous one
     barrier()
     p0 = time.perf_counter()
     h.submit_resident(0, t + 1, t + 1 + 1e-3)

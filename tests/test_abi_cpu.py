@@ -37,7 +37,7 @@ def test_header_cites_reference_lines():
 def test_struct_sizes_match_header_layout():
     import ctypes as C
     assert C.sizeof(_native.Config) == 120
-    assert _native.Config.keep_activations.offset == 112
+    assert _native.Config.keep_activations.offset == 112 and _native.Config.lanes.offset == 116
     assert _native.Config.scales.offset == 16
     assert C.sizeof(_native.LayerInfo) == 64 + 7 * 4 + 4 + 16
 

@@ -271,23 +271,35 @@ def test_end_to_end_vs_oracle(h3, ref3, oracle_net):
     print("worst 3-D excess over tolerance:", worst3)
 
 
-def test_pipelined_submit_collect_equals_sequential(weights):
+@pytest.mark.parametrize("lanes,graph", [(1, True), (2, True), (2, False)])
+def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
+    """Two frames in flight (submit k+1 before collecting k) return exactly what one-at-a-time inference returns: on one
+    lane (same stream), and on two lanes (lanes=2: the frames overlap on two streams / activation arenas and only the
+    joints kernels -- the OneEuro filter chain -- are ordered by an event).  Frames of different sizes alternate, so each
+    lane keeps its own crop geometry; 12 frames exercise both lanes and the 4-deep result ring several times."""
     from tests import helpers
-    frames = [helpers.synth_frame(500 + k, smooth=True) for k in range(4)]
-    a = _handle(BASELINE_SCALES, weights)
+    shapes = [(368, 368), (300, 420), (368, 368), (410, 260)]
+    frames = [helpers.synth_frame(500 + k, *shapes[k], smooth=True) for k in range(4)]
+    a = _handle(BASELINE_SCALES, weights, lanes=lanes, use_graph=graph)
     b = _handle(BASELINE_SCALES, weights, use_graph=False)
     for k, f in enumerate(frames):
         a.upload_frame(k, f)
         b.upload_frame(k, f)
-    seq = [b.infer_resident(k, T0 + k / 30, T0 + k / 30 + 0.001) for k in range(4)]
+    n = 12
+    seq = [b.infer_resident(k % 4, T0 + k / 30, T0 + k / 30 + 0.001) for k in range(n)]
     a.submit_resident(0, T0, T0 + 0.001)
     got = []
-    for k in range(1, 4):
-        a.submit_resident(k, T0 + k / 30, T0 + k / 30 + 0.001)
+    for k in range(1, n):
+        a.submit_resident(k % 4, T0 + k / 30, T0 + k / 30 + 0.001)
         got.append(a.collect())
     got.append(a.collect())
-    for (g2, g3), (s2, s3) in zip(got, seq):
-        assert np.array_equal(g2, s2) and np.array_equal(g3, s3)  # graph replay == eager launches, bit for bit
+    for k, ((g2, g3), (s2, s3)) in enumerate(zip(got, seq)):
+        assert np.array_equal(g2, s2) and np.array_equal(g3, s3), k  # bit for bit
+    # back to one at a time on the same handle: the filter chain continues across the mode change
+    k = n
+    g2, g3 = a.infer_resident(1, T0 + k / 30, T0 + k / 30 + 0.001)
+    s2, s3 = b.infer_resident(1, T0 + k / 30, T0 + k / 30 + 0.001)
+    assert np.array_equal(g2, s2) and np.array_equal(g3, s3)
     a.close(), b.close()
 
 

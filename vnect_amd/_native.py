@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("scales", C.c_double * MAX_SCALES), ("precision", C.c_int32), ("paper_res2c", C.c_int32),
                 ("use_graph", C.c_int32), ("numpy_promotion", C.c_int32), ("max_frame_bytes", C.c_int32),
                 ("num_frame_slots", C.c_int32), ("pyramid_nranks", C.c_int32), ("pyramid_rank", C.c_int32),
-                ("keep_activations", C.c_int32)]
+                ("keep_activations", C.c_int32), ("lanes", C.c_int32)]
 
 
 class Timings(C.Structure):
@@ -107,7 +107,7 @@ class Handle:
     """Thin RAII wrapper over vnect_handle; every method maps 1:1 to a C entry point."""
 
     def __init__(self, scales, device=0, precision=FP32, paper_res2c=False, use_graph=True, numpy_promotion=0,
-                 max_frame_bytes=0, num_frame_slots=0, pyramid=None, keep_activations=False):
+                 max_frame_bytes=0, num_frame_slots=0, pyramid=None, keep_activations=False, lanes=1):
         L = lib()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -117,6 +117,7 @@ class Handle:
             cfg.scales[i] = float(s)
         cfg.precision, cfg.paper_res2c, cfg.use_graph = precision, int(paper_res2c), int(use_graph)
         cfg.numpy_promotion, cfg.max_frame_bytes, cfg.num_frame_slots = numpy_promotion, max_frame_bytes, num_frame_slots
+        cfg.lanes = int(lanes)  # 2: submit_resident/collect overlap two frames on two lanes
         cfg.keep_activations = int(keep_activations)  # True: activation(name) can return inner layers (tests)
         if pyramid is not None:  # (rank, nranks): this handle runs one scale of the pyramid (vnect_comm_init)
             cfg.pyramid_rank, cfg.pyramid_nranks = int(pyramid[0]), int(pyramid[1])

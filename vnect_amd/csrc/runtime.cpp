@@ -75,6 +75,13 @@ struct vnect_handle {
     size_t param_left = 0;
     bool keep_activations = true;  // one private buffer per layer output (vnect_read_activation needs it); false = arena
     size_t arena_bytes = 0;
+    std::vector<size_t> arena_off;  // byte offset of every tensor in the arena
+    // Second lane (cfg.lanes == 2): a frame submitted while another is in flight runs on `twin` -- its own stream, activation
+    // arena, split-K workspace, arg-max scratch and graph; weights, tables, resident frames, the result ring and the filter
+    // bank are this handle's.  The two frames overlap everywhere except in the joints kernel (the filters are a chain).
+    vnect_handle* twin = nullptr;
+    bool is_twin = false;
+    vnect_handle* last_lane = nullptr;  // lane of the most recently submitted frame
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; };
@@ -543,6 +550,17 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     return L.out;
 }
 
+// point a conv layer's arguments at h's activation buffers and workspace (weights are whatever L already holds)
+void bind_activations(vnect_handle* h, Layer& L)
+{
+    ConvArgs& a = L.a;
+    a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
+    a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
+    a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
+    a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws, a.zeros = h->zeros;
+    L.r.ws = h->ws, L.r.resid = a.resid, L.r.out = a.out;
+}
+
 int finalize_impl(vnect_handle* h)
 {
     const int S = h->Snet;
@@ -756,7 +774,7 @@ int finalize_impl(vnect_handle* h)
         if (rc) return rc;
         HIPCK(h, hipMemset(base, 0, total));
         for (int t = 0; t < nt; t++) h->tensors[t].d = (float*)(base + off[t]);
-        h->arena_bytes = total;
+        h->arena_bytes = total, h->arena_off = off;
     } else {
         for (Tensor& t : h->tensors) {
             char* p = nullptr;
@@ -785,10 +803,7 @@ int finalize_impl(vnect_handle* h)
     for (Layer& L : h->layers) {
         if (L.op != OP_CONV) continue;
         ConvArgs& a = L.a;
-        a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
-        a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
-        a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
-        a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws, a.zeros = h->zeros;
+        bind_activations(h, L);
         {   // tap byte offsets for the buffer-addressed loads (kernels.h)
             const int esz = a.bf16 ? 2 : 4, nt = a.nphase * a.ntaps;
             int lo = 0;
@@ -812,7 +827,7 @@ int finalize_impl(vnect_handle* h)
         }
         if (a.ksplit > 1) {
             ReduceArgs& q = L.r;
-            q.ws = h->ws, q.bias = L.bias, q.scale = L.scale, q.shift = L.shift, q.resid = a.resid, q.out = a.out;
+            q.bias = L.bias, q.scale = L.scale, q.shift = L.shift;
             a.slab_pix = (long long)a.S * a.OH * a.OW + 64, q.slab_pix = a.slab_pix;
             q.npix = (long long)a.S * a.OH * a.OW, q.Npad = a.Npad, q.Nvalid = a.Nvalid, q.ldc = a.ldc, q.ldr = a.ldr;
             q.ksplit = a.ksplit, q.relu_cols = a.relu_cols;
@@ -975,6 +990,7 @@ int build_graph(vnect_handle* h)
     if (rc) return rc;
     HIPCK(h, e);
     HIPCK(h, hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+    if (h->is_twin) return VNECT_OK;  // profiled frames always run on the first lane
     // profiling twin: identical launches, but every conv kernel stamps {min start, max end} (s_memrealtime)
     HIPCK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
     rc = run_frame_kernels(h, true);
@@ -982,6 +998,56 @@ int build_graph(vnect_handle* h)
     if (rc) return rc;
     HIPCK(h, e);
     HIPCK(h, hipGraphInstantiate(&h->pgexec, h->pgraph, nullptr, nullptr, 0));
+    return VNECT_OK;
+}
+
+void destroy_twin(vnect_handle* h)
+{
+    vnect_handle* t = h->twin;
+    if (!t) return;
+    if (t->st) hipStreamSynchronize(t->st);
+    if (t->gexec) hipGraphExecDestroy(t->gexec);
+    if (t->graph) hipGraphDestroy(t->graph);
+    for (int i = 0; i < RING; i++)
+        if (t->h_fp[i]) hipHostFree(t->h_fp[i]);
+    for (void* p : t->dev_allocs) hipFree(p);
+    if (t->st) hipStreamDestroy(t->st);
+    delete t;
+    h->twin = nullptr;
+}
+
+// The second lane of a two-deep pipeline (vnect_config::lanes == 2): same layers and weights, its own stream, activation
+// arena, workspace, arg-max scratch, geometry block and graph.
+int build_twin(vnect_handle* h)
+{
+    destroy_twin(h);
+    if (h->cfg.lanes != 2 || h->sharded || h->keep_activations) return VNECT_OK;
+    vnect_handle* t = new vnect_handle();
+    h->twin = t;
+    t->is_twin = true;
+    t->cfg = h->cfg, t->S = h->S, t->Snet = h->Snet, t->bf16 = h->bf16, t->keep_activations = false;
+    HIPCK(h, hipStreamCreateWithFlags(&t->st, hipStreamNonBlocking));
+    // shared: read-only tables and frames; the filter bank (its users are chained by events)
+    t->frames = h->frames, t->d_stabs = h->d_stabs, t->d_mtabs = h->d_mtabs, t->d_up = h->d_up, t->d_fb = h->d_fb, t->zeros = h->zeros;
+    t->slots = h->slots;
+    int rc;
+    if ((rc = dev_alloc(t, &t->d_fp, 1))) return fail(h, rc, t->err);
+    if ((rc = dev_alloc(t, &t->d_part, (size_t)NJ * ARG_SLABS))) return fail(h, rc, t->err);
+    if ((rc = dev_alloc(t, &t->d_hm, (size_t)NJ * HM * HM))) return fail(h, rc, t->err);
+    for (int i = 0; i < RING; i++) HIPCK(h, hipHostMalloc((void**)&t->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
+    t->tensors = h->tensors, t->layers = h->layers, t->tensor_by_name = h->tensor_by_name;
+    t->t_input4 = h->t_input4, t->t_out = h->t_out;
+    char* base = nullptr;
+    if ((rc = dev_alloc(t, &base, h->arena_bytes))) return fail(h, rc, t->err);
+    HIPCK(h, hipMemset(base, 0, h->arena_bytes));
+    for (size_t i = 0; i < t->tensors.size(); i++) t->tensors[i].d = (float*)(base + h->arena_off[i]);
+    t->ws_floats = h->ws_floats;
+    if (t->ws_floats && (rc = dev_alloc(t, &t->ws, t->ws_floats))) return fail(h, rc, t->err);
+    for (Layer& L : t->layers)
+        if (L.op == OP_CONV) bind_activations(t, L);
+    t->finalized = true;
+    if ((rc = build_graph(t))) return fail(h, rc, t->err);
+    HIPCK(h, hipStreamSynchronize(t->st));
     return VNECT_OK;
 }
 
@@ -1004,21 +1070,28 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     dyn.t2d = t2d, dyn.t3d = t3d;
     dyn.row_stride = si.stride;
     dyn.frame = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
-    if ((rc = sync_geometry(h, fp))) return rc;
     const bool timed = h->profiling;
-    if (timed) HIPCK(h, hipEventRecord(h->ev[0], h->st));
-    if ((rc = run_pre(h, dyn))) return rc;
-    if (h->gexec && !timed) {
-        HIPCK(h, hipGraphLaunch(h->gexec, h->st));
-    } else if (h->pgexec && timed) {
-        HIPCK(h, hipGraphLaunch(h->pgexec, h->st));
+    // Lane: the first one, unless a frame is still in flight there and a second lane exists -- then the two frames overlap
+    // (the idle CUs between one frame's launches are the other frame's), and only the joints kernels stay in order.
+    vnect_handle* L = h;
+    if (h->twin && !timed && h->seq_submit != h->seq_collect && h->last_lane == h) L = h->twin;
+    if ((rc = sync_geometry(L, fp))) return fail(h, rc, L->err);
+    if (timed) HIPCK(h, hipEventRecord(h->ev[0], L->st));
+    if ((rc = run_pre(L, dyn))) return fail(h, rc, L->err);
+    if (L->gexec && !timed) {
+        HIPCK(h, hipGraphLaunch(L->gexec, L->st));
+    } else if (L->pgexec && timed) {
+        HIPCK(h, hipGraphLaunch(L->pgexec, L->st));
     } else {
-        rc = run_frame_kernels(h, timed);
-        if (rc) return rc;
+        rc = run_frame_kernels(L, timed);
+        if (rc) return fail(h, rc, L->err);
     }
-    if ((rc = run_joints(h, dyn, h->h_out_dev[ring]))) return rc;  // writes the ring slot in pinned host memory
-    if (timed) HIPCK(h, hipEventRecord(h->ev[3], h->st));
-    HIPCK(h, hipEventRecord(h->done[ring], h->st));
+    if (h->seq_submit > 0 && h->last_lane && h->last_lane != L)  // the filters are a chain: frame k's state feeds frame k+1
+        HIPCK(h, hipStreamWaitEvent(L->st, h->done[(h->seq_submit - 1) % RING], 0));
+    if ((rc = run_joints(L, dyn, h->h_out_dev[ring]))) return fail(h, rc, L->err);  // writes the ring slot in pinned host memory
+    if (timed) HIPCK(h, hipEventRecord(h->ev[3], L->st));
+    HIPCK(h, hipEventRecord(h->done[ring], L->st));
+    h->last_lane = L;
     h->seq_submit++;
     *ring_out = ring;
     return VNECT_OK;
@@ -1070,6 +1143,7 @@ int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int 
     uint8_t* dst = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
     // a frame still being read by an in-flight inference must not be overwritten
     HIPCK(h, hipStreamSynchronize(h->st));
+    if (h->twin) HIPCK(h, hipStreamSynchronize(h->twin->st));
     HIPCK(h, hipMemcpy2D(dst, (size_t)W * 3, bgr, (size_t)row_stride, (size_t)W * 3, H, hipMemcpyHostToDevice));
     h->slots[slot].H = H, h->slots[slot].W = W, h->slots[slot].stride = (long long)W * 3;
     return VNECT_OK;
@@ -1150,6 +1224,7 @@ void vnect_destroy(vnect_handle* h)
     if (!h) return;
     hipSetDevice(h->cfg.device);
     if (h->st) hipStreamSynchronize(h->st);
+    destroy_twin(h);
     if (h->comm && p_ncclCommDestroy) p_ncclCommDestroy(h->comm);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     if (h->graph) hipGraphDestroy(h->graph);
@@ -1198,6 +1273,8 @@ int vnect_finalize(vnect_handle* h)
     }
     rc = build_graph(h);
     if (rc) return rc;
+    rc = build_twin(h);
+    if (rc) return rc;
     HIPCK(h, hipStreamSynchronize(h->st));
     h->finalized = true;
     h->weights.clear();
@@ -1211,6 +1288,7 @@ int vnect_set_scales(vnect_handle* h, const double* scales, int n)
     if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
     HIPCK(h, hipSetDevice(h->cfg.device));
     HIPCK(h, hipStreamSynchronize(h->st));
+    if (h->twin) HIPCK(h, hipStreamSynchronize(h->twin->st));
     double old[VNECT_MAX_SCALES];
     memcpy(old, h->cfg.scales, sizeof old);
     for (int i = 0; i < n; i++) h->cfg.scales[i] = scales[i];
