@@ -303,6 +303,30 @@ def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
     a.close(), b.close()
 
 
+def test_estimator_submit_collect_two_lanes(weights):
+    """The facade's additive pipelined API (submit / collect, lanes=2) against its own frame-by-frame __call__, with frames
+    uploaded from host memory each time (an upload waits only for the inference that still reads its slot)."""
+    from tests import helpers
+    from vnect_amd import VNectEstimator
+    frames = [helpers.synth_frame(900 + k, 368 - 11 * (k % 3), 300 + 17 * (k % 4), smooth=True) for k in range(9)]
+    one = VNectEstimator(scales=BASELINE_SCALES, weights=weights, verbose=False)
+    two = VNectEstimator(scales=BASELINE_SCALES, weights=weights, verbose=False, lanes=2)
+    want = [one(f, timestamp=T0 + k / 30) for k, f in enumerate(frames)]
+    got = []
+    two.submit(frames[0], timestamp=T0)
+    for k in range(1, len(frames)):
+        two.submit(frames[k], timestamp=T0 + k / 30)
+        got.append(two.collect())
+    got.append(two.collect())
+    for k, ((g2, g3), (w2, w3)) in enumerate(zip(got, want)):
+        assert np.array_equal(g2, w2) and np.array_equal(g3, w3), k
+    with pytest.raises(_native().VnectError):  # a third frame in flight is refused, state untouched
+        two.submit(frames[0], timestamp=T0 + 1)
+        two.submit(frames[1], timestamp=T0 + 2)
+        two.submit(frames[2], timestamp=T0 + 3)
+    one.close(), two.close()
+
+
 def test_errors_mirror_reference(weights):
     from vnect_amd import VNectEstimator
     est = VNectEstimator(scales=[1.0], weights=weights, verbose=False)

