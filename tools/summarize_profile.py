@@ -29,7 +29,7 @@ if st:
     rows = list(csv.DictReader(open(st)))
     with open(os.path.join(sumdir, rnd + "_kernel_stats.csv"), "w") as f:
         f.write(open(st).read())
-    conv = [r for r in rows if "conv_glds" in r["Name"] or "conv_stream" in r["Name"]]
+    conv = [r for r in rows if "conv_stream" in r["Name"]]
     calls = sum(int(r["Calls"]) for r in conv)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in conv)
     allk = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -66,10 +66,10 @@ if ft and wt and res.get("frames_profiled"):
     per_kernel = {}
     for k in sorted(set(ft) | set(wt)):
         per_kernel[k] = {"fetch_KB_raw_per_frame": ft.get(k, 0) / fr, "write_KB_per_frame": wt.get(k, 0) / fr}
-    conv_f = sum(v for k, v in ft.items() if "conv_glds" in k or "conv_stream" in k) / fr
-    conv_w = sum(v for k, v in wt.items() if "conv_glds" in k or "conv_stream" in k) / fr
+    conv_f = sum(v for k, v in ft.items() if "conv_stream" in k) / fr
+    conv_w = sum(v for k, v in wt.items() if "conv_stream" in k) / fr
     traffic = {
-        "note": "per frame, conv kernels (conv_stream / conv_glds) only; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request), WRITE_SIZE as is; units KB=1024 B",
+        "note": "per frame, conv_stream_kernel launches only (all tile shapes, profiling twins included); FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request), WRITE_SIZE as is; units KB=1024 B",
         "fetch_bytes_per_frame": conv_f * 2 * 1024, "write_bytes_per_frame": conv_w * 1024,
         "hbm_bytes_per_frame": (conv_f * 2 + conv_w) * 1024, "per_kernel": per_kernel}
     json.dump(traffic, open(os.path.join(sumdir, rnd + "_traffic.json"), "w"), indent=1)

@@ -97,7 +97,6 @@ struct vnect_handle {
     ArgPartial* d_part = nullptr;
     double* d_hm = nullptr;  // merged heat-maps, joint-major (21,46,46) f64
     FilterBank* d_fb = nullptr;
-    JointsOut* d_out = nullptr;
     JointsOut* h_out[RING] = {};   // pinned, device-mapped: joints_kernel writes a frame's results straight into its ring slot
     JointsOut* h_out_dev[RING] = {};  // the same slots as the device addresses them
     hipEvent_t done[RING] = {};
@@ -886,7 +885,7 @@ int run_argmax(vnect_handle* h)
     return VNECT_OK;
 }
 
-// filters + read-off; results go straight to `out` (a device-mapped pinned host slot, or d_out)
+// filters + read-off; results go straight to `out` (a device-mapped pinned host slot)
 int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
@@ -1200,7 +1199,6 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
     if ((rc = dev_alloc(h, &h->d_hm, (size_t)NJ * HM * HM))) return rc;
     if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->d_out, 1))) return rc;
     if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
     if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
     for (int i = 0; i < RING; i++) {
