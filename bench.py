@@ -116,11 +116,14 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
+    stamps = [t0]
     for i in range(args.steps):
         t += 1 / 30
         j2, j3 = h.infer_resident(i % nslots, t, t + 1e-3)
+        stamps.append(time.perf_counter())  # per-frame latency distribution (median + p95)
     barrier()
     elapsed = time.perf_counter() - t0
+    lat = np.diff(np.array(stamps)) * 1e3
     elapsed = grp.max_over_ranks(elapsed)
     assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
 
@@ -207,6 +210,8 @@ def main():
                        "weights": "seeded synthetic (reference ships none)", "frames_resident_in_hbm": True,
                        "hip_graph": not args.no_graph and not args.pyramid, "sync_per_frame": True,
                        "parallelism": "pyramid: 1 scale per GPU + RCCL all-gather" if args.pyramid else "stream replicas"},
+            "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p95": round(float(np.percentile(lat, 95)), 4),
+                           "max": round(float(lat.max()), 4)},
             "pipelined_frames_per_s_per_gpu": round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
             "roofline": dict(
