@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-aux", action="store_true",
+                    help="skip the auxiliary legs (PCIe-inclusive, two frames in flight, two streams per GPU): they overlap "
+                         "kernels by design, so a rocprofv3 run meant to describe the synchronous headline loop uses this")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE.json configs[1] (default, the headline); bf16 = configs[2] (bf16 MFMA conv path)")
     ap.add_argument("--pyramid", action="store_true",
@@ -129,22 +132,24 @@ def main():
 
     # two-deep pipelined rate of the same stream (submit k+1 before collecting k; the frames overlap on two lanes, only the
     # filter kernels stay ordered), reported beside the synchronous one
-    barrier()
-    p0 = time.perf_counter()
-    h.submit_resident(0, t + 1, t + 1 + 1e-3)
-    for i in range(1, args.steps):
-        h.submit_resident(i % nslots, t + 1 + i / 30, t + 1 + i / 30 + 1e-3)
+    pipelined = None
+    if not args.no_aux:
+        barrier()
+        p0 = time.perf_counter()
+        h.submit_resident(0, t + 1, t + 1 + 1e-3)
+        for i in range(1, args.steps):
+            h.submit_resident(i % nslots, t + 1 + i / 30, t + 1 + i / 30 + 1e-3)
+            h.collect()
         h.collect()
-    h.collect()
-    torch.cuda.synchronize()
-    pipelined = args.steps / (time.perf_counter() - p0)
+        torch.cuda.synchronize()
+        pipelined = args.steps / (time.perf_counter() - p0)
     t += 1 + args.steps / 30 + 1
 
     # the same synchronous loop fed from HOST memory (vnect_infer: a pageable 406 KB frame crosses PCIe every step) --
     # the rate a caller of VNectEstimator.__call__ sees; never `value` (whose frames are resident in HBM)
     host_frames = [helpers.synth_frame(stream_seed(0 if args.pyramid else rank, k)) for k in range(nslots)]
     pcie = None
-    if not args.pyramid:
+    if not args.pyramid and not args.no_aux:
         nh = max(args.steps // 3, 20)
         for i in range(5):
             t += 1 / 30
@@ -161,7 +166,7 @@ def main():
     # two independent video streams sharing this GPU (two handles, two host threads): what the idle CUs between the
     # launches of one synchronous stream are worth.  Reported beside the headline, never as `value`.
     two_streams = None
-    if not args.pyramid and rank == 0:
+    if not args.pyramid and rank == 0 and not args.no_aux:
         import threading
         h2 = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec)
         h2.set_weights(weights)
@@ -202,7 +207,11 @@ def main():
         tim = h.timings()
         h.set_profiling(False)
     if rank == 0:
-        conv_ms = tim["conv_ms"] / nprof
+        # Per-launch duration = the SLOT a conv kernel occupies on the stream (its start to the next kernel's start): that is
+        # what rocprofv3 reports per kernel (dispatch -> completion, durations abut) and what a launch costs the frame.  The
+        # first-wave-start .. last-wave-end time of the same launches is carried beside it.
+        conv_ms = tim["conv_slot_ms"] / nprof
+        exec_ms = tim["conv_ms"] / nprof
         achieved = FLOPS_PER_FRAME / (len(SCALES) if args.pyramid else 1) / (conv_ms * 1e-3) / 1e12  # per GPU
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -231,7 +240,7 @@ def main():
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p95": round(float(np.percentile(lat, 95)), 4),
                            "max": round(float(lat.max()), 4)},
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
-            "pipelined_frames_per_s_per_gpu": round(pipelined, 2),
+            "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
             "roofline": dict(
                          # fp32: the conv stack is MFMA-bound.  bf16: 16x the MFMA rate makes the
@@ -249,6 +258,9 @@ def main():
                                 % ("false" if args.precision == "fp32" else "true", tim["conv_launches"]),
                          launches_per_frame=tim["conv_launches"],
                          avg_launch_us=round(conv_ms * 1e3 / tim["conv_launches"], 3),
+                         first_to_last_wave={"avg_launch_us": round(exec_ms * 1e3 / tim["conv_launches"], 3),
+                                             "achieved": round(FLOPS_PER_FRAME / (len(SCALES) if args.pyramid else 1) / (exec_ms * 1e-3) / 1e12, 3),
+                                             "frac": round(FLOPS_PER_FRAME / (len(SCALES) if args.pyramid else 1) / (exec_ms * 1e-3) / 1e12 / peak, 4)},
                          rocprofv3_avg_launch_us=None if rocprof_us is None else round(rocprof_us, 3),
                          kernel_ms_per_frame=round(conv_ms, 4), flops_per_frame=FLOPS_PER_FRAME,
                          conv_stack_span_ms=round(tim["net_ms"] / nprof, 4),

@@ -132,6 +132,10 @@ typedef struct vnect_timings {
     double conv_ms;            /* sum of the conv kernels' own durations (device clock, like rocprofv3), summed    */
     int32_t conv_launches;     /* conv kernel launches per frame                                                   */
     double conv_flops;         /* algorithmic conv FLOPs per frame (2*MAC, live graph)                             */
+    double conv_slot_ms;       /* sum over the conv kernels of the slot each one occupies on the stream: its start to the
+                                  start of the kernel behind it (own duration + median boundary where another kind of
+                                  kernel follows).  rocprofv3's per-kernel durations abut the same way (dispatch ->
+                                  completion), so this is the figure its --stats average agrees with.  Summed.          */
 } vnect_timings;
 /* Profiling replays a twin of the frame graph in which every conv kernel stamps its start and end with the
  * 100 MHz device clock (s_memrealtime); off by default, no cost when off. */

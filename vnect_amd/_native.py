@@ -34,7 +34,7 @@ class Config(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("frames", C.c_int32), ("total_ms", C.c_double), ("net_ms", C.c_double),
-                ("conv_ms", C.c_double), ("conv_launches", C.c_int32), ("conv_flops", C.c_double)]
+                ("conv_ms", C.c_double), ("conv_launches", C.c_int32), ("conv_flops", C.c_double), ("conv_slot_ms", C.c_double)]
 
 
 class LayerInfo(C.Structure):

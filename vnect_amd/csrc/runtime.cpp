@@ -1127,6 +1127,33 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
             conv_ms += L.last_ms;
             first = std::min(first, t0), last = std::max(last, t1);
         }
+        // slot of a conv kernel on the stream: its start to the next conv kernel's start when that one follows directly,
+        // else its own duration + the median boundary of the direct pairs (pool / reduce / bone / arg-max follow it)
+        std::vector<double> gaps;
+        std::vector<size_t> convs;
+        for (size_t i = 0; i < h->layers.size(); i++)
+            if (h->layers[i].op == OP_CONV && h->layers[i].last_ms > 0) convs.push_back(i);
+        auto t_start = [&](size_t i) { return h->h_prof[PROF_SLOTS * i]; };
+        auto t_end = [&](size_t i) {
+            unsigned long long e = 0;
+            for (int k = 1; k <= 8; k++) e = std::max(e, h->h_prof[PROF_SLOTS * i + k]);
+            return e;
+        };
+        auto direct = [&](size_t a, size_t b) { return b == a + 1 && h->layers[a].a.ksplit == 1; };  // no kernel in between
+        for (size_t c = 0; c + 1 < convs.size(); c++)
+            if (direct(convs[c], convs[c + 1]) && t_start(convs[c + 1]) > t_end(convs[c]))
+                gaps.push_back((double)(t_start(convs[c + 1]) - t_end(convs[c])) * 1e-5);
+        std::sort(gaps.begin(), gaps.end());
+        const double med_gap = gaps.empty() ? 0.0 : gaps[gaps.size() / 2];
+        double slot_ms = 0;
+        for (size_t c = 0; c < convs.size(); c++) {
+            const size_t i = convs[c];
+            if (c + 1 < convs.size() && direct(i, convs[c + 1]) && t_start(convs[c + 1]) > t_start(i))
+                slot_ms += (double)(t_start(convs[c + 1]) - t_start(i)) * 1e-5;
+            else
+                slot_ms += h->layers[i].last_ms + med_gap;
+        }
+        h->tim.conv_slot_ms += slot_ms;
         h->tim.frames++;
         h->tim.total_ms += frame_ms;                                     // HIP events around the whole frame
         h->tim.net_ms += last > first ? (double)(last - first) * 1e-5 : 0;  // first conv start .. last conv end
