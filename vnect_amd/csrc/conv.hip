@@ -116,7 +116,9 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
     const int kg = wave / WMN, wr = wave % WMN, wm = wr / BRB, wn = wr % BRB;  // consumers: K group, tile row / column block
-    if (P1 && threadIdx.x == 0 && blockIdx.x < 8) atomicMin(prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    // start stamp: workgroup 0 (first dispatched; a grid starts first -> last within ~0.5 us).  Plain store: nothing in the
+    // twin may queue behind an atomic.
+    if (P1 && threadIdx.x == 0 && blockIdx.x == 0) prof[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     const bool pstamp = P2 && threadIdx.x == 0 && blockIdx.x == 0;
     if (pstamp) prof[9] = __builtin_amdgcn_s_memrealtime();
     if (P2 && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -534,9 +536,11 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     }
     if (pstamp) prof[12] = __builtin_amdgcn_s_memrealtime(), prof[19] = cbw;
     if (P1 && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+        // PROF = 1 stamps the end when this wave's last store has been ISSUED: waiting for the stores first (PROF = 2 does, for
+        // its "stores drained" stamp) puts a store round trip in front of the stamp's own store in every workgroup
+        if constexpr (P2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (pstamp) prof[13] = __builtin_amdgcn_s_memrealtime();
-        atomicMax(prof + 1 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        if (blockIdx.x < PROF_WGS) a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 

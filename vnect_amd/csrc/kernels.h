@@ -11,6 +11,7 @@ constexpr int NJ = 21;
 constexpr int MAPC = 84;       // 4 maps x 21 joints
 constexpr int MAX_TAPS = 16;
 constexpr int ARG_SLABS = 8;    // arg-max workgroups per joint (6 row segments each)
+constexpr int PROF_WGS = 512;   // largest conv grid (two workgroups per CU)
 constexpr int PROF_SLOTS = 24;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
@@ -26,7 +27,9 @@ struct ConvArgs {
     float* out2;          // second output tensor for columns >= split_n (two layers sharing one input), or nullptr
     float* ws;            // split-K workspace [ksplit][slab_pix][Npad]
     long long slab_pix;   // pixels per slab: out pixels + 64 of slack (the last tile's rows past M land there)
-    unsigned long long* prof;  // nullptr, or {min start, 8 x max end} of this launch in 100 MHz s_memrealtime ticks
+    unsigned long long* prof;  // nullptr, or {min start, ...} of this launch in 100 MHz s_memrealtime ticks
+    unsigned long long* prof_end;  // profiling twin: [PROF_WGS] end stamp of every workgroup (plain stores: an atomic max
+                                   // over 500 workgroups put ~1.4 us behind every launch); the host takes the maximum
     const float* zeros;   // >= 128 B of zeros (source of padded taps / rows past M for the LDS-DMA loads)
     int S, H, W, Cs;      // input grid, floats per input pixel
     int Ho, Wo, M;        // logical output grid, M = S*Ho*Wo

@@ -114,6 +114,8 @@ struct vnect_handle {
     unsigned long long* d_prof = nullptr;       // [layer][2] device stamps (100 MHz)
     unsigned long long* h_prof = nullptr;       // pinned read-back
     unsigned long long* h_prof_init = nullptr;  // pinned {~0, 0} pattern
+    unsigned long long* d_prof_end = nullptr;   // [128 layers][PROF_WGS] per-workgroup end stamps of the profiling twin
+    unsigned long long* h_prof_end = nullptr;   // pinned read-back
     // profiling
     bool profiling = false;
     hipEvent_t ev[4] = {};
@@ -845,6 +847,7 @@ int run_network(vnect_handle* h, bool timed)
         if (L.op == OP_CONV) {
             ConvArgs a = L.a;
             a.prof = timed ? h->d_prof + PROF_SLOTS * (&L - h->layers.data()) : nullptr;
+            a.prof_end = timed ? h->d_prof_end + (size_t)PROF_WGS * (&L - h->layers.data()) : nullptr;
             HIPCK(h, launch_conv(a, L.BM, L.BN, L.KG, h->st));
             if (L.a.ksplit > 1) HIPCK(h, launch_reduce(L.r, h->st));
         } else if (L.op == OP_POOL) {
@@ -966,13 +969,15 @@ int all_gather_maps(vnect_handle* h)
 int run_frame_kernels(vnect_handle* h, bool timed)
 {
     const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
-    if (timed) HIPCK(h, hipMemcpyAsync(h->d_prof, h->h_prof_init, pbytes, hipMemcpyHostToDevice, h->st));
     int rc = run_network(h, timed);
     if (rc) return rc;
     if (h->sharded && (rc = all_gather_maps(h))) return rc;
     rc = run_argmax(h);
     if (rc) return rc;
-    if (timed) HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
+    if (timed) {
+        HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
+        HIPCK(h, hipMemcpyAsync(h->h_prof_end, h->d_prof_end, h->layers.size() * PROF_WGS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
+    }
     return VNECT_OK;
 }
 
@@ -1117,10 +1122,14 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
         double conv_ms = 0;
         for (size_t i = 0; i < h->layers.size(); i++) {
             Layer& L = h->layers[i];
-            const unsigned long long* p = h->h_prof + PROF_SLOTS * i;
+            unsigned long long* p = h->h_prof + PROF_SLOTS * i;
             const unsigned long long t0 = p[0];
             unsigned long long t1 = 0;
-            for (int k = 1; k <= 8; k++) t1 = std::max(t1, p[k]);
+            if (L.op == OP_CONV) {  // latest workgroup end of this launch (slots past the grid stay 0)
+                const unsigned long long* e = h->h_prof_end + (size_t)PROF_WGS * i;
+                for (int k = 0; k < PROF_WGS; k++) t1 = std::max(t1, e[k]);
+                for (int k = 1; k <= 8; k++) p[k] = t1;  // vnect_get_layer_stamps keeps its layout
+            }
             L.last_ms = 0;
             if (L.op != OP_CONV || t1 <= t0) continue;
             L.last_ms = (float)((double)(t1 - t0) * 1e-5);  // 100 MHz ticks -> ms
@@ -1236,6 +1245,9 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     }
     for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
     if ((rc = dev_alloc(h, &h->d_prof, PROF_SLOTS * 128))) return rc;
+    if ((rc = dev_alloc(h, &h->d_prof_end, (size_t)PROF_WGS * 128))) return rc;
+    HIPCK(h, hipMemset(h->d_prof_end, 0, (size_t)PROF_WGS * 128 * sizeof(unsigned long long)));
+    HIPCK(h, hipHostMalloc((void**)&h->h_prof_end, (size_t)PROF_WGS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCK(h, hipHostMalloc((void**)&h->h_prof, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCK(h, hipHostMalloc((void**)&h->h_prof_init, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
     for (int i = 0; i < PROF_SLOTS * 128; i++) h->h_prof_init[i] = (i % PROF_SLOTS) == 0 ? ~0ull : 0, h->h_prof[i] = 0;
@@ -1266,6 +1278,7 @@ void vnect_destroy(vnect_handle* h)
         if (e) hipEventDestroy(e);
     if (h->h_prof) hipHostFree(h->h_prof);
     if (h->h_prof_init) hipHostFree(h->h_prof_init);
+    if (h->h_prof_end) hipHostFree(h->h_prof_end);
     for (void* p : h->dev_allocs) hipFree(p);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
