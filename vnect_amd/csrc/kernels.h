@@ -154,8 +154,8 @@ struct JointsOut {
     int status;
 };
 
-hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, double* hm, ArgPartial* part,
-                         hipStream_t st);
+// multi-scale merge of the heat-maps (in LDS, the rows each workgroup needs) + arg-max of the virtual x8 upsample
+hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st);
 // out may be (device-mapped) pinned HOST memory: the kernel's 21x2 + 21x3 results then need no device-to-host copy
 hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
                          const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st);

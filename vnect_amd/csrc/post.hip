@@ -133,17 +133,6 @@ __device__ __forceinline__ double merged_cell(const float* __restrict__ maps, co
     return acc / (double)S;
 }
 
-// Merged heat-maps only (map 0 of estimator.py:105-129), written joint-major [j][r][c] so that the arg-max workgroup
-// of a joint reads one contiguous 46x46 plane.  Threads run channel-fastest: the NHWC reads are 84-byte runs.
-__global__ __launch_bounds__(256) void merge_heat_kernel(const float* __restrict__ maps, const MergeTabs* __restrict__ tabs,
-                                                         int S, double* __restrict__ hm)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= HM * HM * NJ) return;
-    const int j = idx % NJ, p = idx / NJ;
-    hm[j * (HM * HM) + p] = merged_cell(maps, tabs, S, j, p / HM, p % HM);
-}
-
 // the merge tables are read many times per thread: copy them to LDS once per workgroup
 __device__ __forceinline__ void stage_merge_tabs(const MergeTabs* __restrict__ g, MergeTabs* l, int S)
 {
@@ -164,7 +153,8 @@ __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { ret
 constexpr int ARG_THREADS = 384;  // one thread per column (368 used)
 constexpr int ARG_SEGS = 6;       // 8-row segments per workgroup: 8 slabs x 6 >= 47 segments, 168 workgroups keep the f64 work off one CU
 
-__global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const double* __restrict__ hm,
+__global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* __restrict__ maps,
+                                                                  const MergeTabs* __restrict__ mtabs, int S,
                                                                   const UpTab* __restrict__ up,
                                                                   ArgPartial* __restrict__ part)
 {
@@ -174,7 +164,16 @@ __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const double* 
     __shared__ double tb0[16], tb1[16];  // the 8 row phases (rows 4..11 of the table)
     const int j = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
     if (tid < 16) tb0[tid] = up->b0[tid], tb1[tid] = up->b1[tid];
-    for (int p = tid; p < HM * HM; p += ARG_THREADS) map[p] = hm[j * (HM * HM) + p];
+    {   // the multi-scale merge (estimator.py:105-129) of exactly the heat-map rows this slab blends: at most 7 of the 46,
+        // one cell per thread -- no separate merge launch, no f64 plane in HBM
+        const int g0 = slab * ARG_SEGS, g1 = g0 + ARG_SEGS < 47 ? g0 + ARG_SEGS : 47;
+        const int r_lo = g0 > 0 ? g0 - 1 : 0, r_hi = g1 - 1 < HM - 1 ? g1 - 1 : HM - 1;
+        const int cells = (r_hi - r_lo + 1) * HM;
+        for (int p = tid; p < cells; p += ARG_THREADS) {
+            const int r = r_lo + p / HM, c = p % HM;
+            map[r * HM + c] = merged_cell(maps, mtabs, S, j, r, c);
+        }
+    }
     __syncthreads();
     // Row structure of the x8 upsample (checked against the table on the host, build_up_table): destination row y
     // belongs to segment g = (y + 4) / 8 and phase p = (y + 4) % 8; it blends source rows max(g-1, 0) and min(g, 45)
@@ -218,11 +217,9 @@ __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const double* 
         part[j * ARG_SLABS + slab].idx = si[0];
     }
 }
-hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, double* hm, ArgPartial* part,
-                         hipStream_t st)
+hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st)
 {
-    hipLaunchKernelGGL(merge_heat_kernel, dim3((HM * HM * NJ + 255) / 256), dim3(256), 0, st, maps, mtabs, S, hm);
-    hipLaunchKernelGGL(heat_argmax_kernel, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, hm, up, part);
+    hipLaunchKernelGGL(heat_argmax_kernel, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part);
     return hipGetLastError();
 }
 

@@ -95,7 +95,6 @@ struct vnect_handle {
     MergeTabs* d_mtabs = nullptr;
     UpTab* d_up = nullptr;
     ArgPartial* d_part = nullptr;
-    double* d_hm = nullptr;  // merged heat-maps, joint-major (21,46,46) f64
     FilterBank* d_fb = nullptr;
     JointsOut* h_out[RING] = {};   // pinned, device-mapped: joints_kernel writes a frame's results straight into its ring slot
     JointsOut* h_out_dev[RING] = {};  // the same slots as the device addresses them
@@ -884,7 +883,7 @@ int run_pre(vnect_handle* h, const FrameDyn& dyn)
 int run_argmax(vnect_handle* h)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, launch_argmax(maps, h->d_mtabs, h->S, h->d_up, h->d_hm, h->d_part, h->st));
+    HIPCK(h, launch_argmax(maps, h->d_mtabs, h->S, h->d_up, h->d_part, h->st));
     return VNECT_OK;
 }
 
@@ -1037,7 +1036,6 @@ int build_twin(vnect_handle* h)
     int rc;
     if ((rc = dev_alloc(t, &t->d_fp, 1))) return fail(h, rc, t->err);
     if ((rc = dev_alloc(t, &t->d_part, (size_t)NJ * ARG_SLABS))) return fail(h, rc, t->err);
-    if ((rc = dev_alloc(t, &t->d_hm, (size_t)NJ * HM * HM))) return fail(h, rc, t->err);
     for (int i = 0; i < RING; i++) HIPCK(h, hipHostMalloc((void**)&t->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
     t->tensors = h->tensors, t->layers = h->layers, t->tensor_by_name = h->tensor_by_name;
     t->t_input4 = h->t_input4, t->t_out = h->t_out;
@@ -1233,7 +1231,6 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
     if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
-    if ((rc = dev_alloc(h, &h->d_hm, (size_t)NJ * HM * HM))) return rc;
     if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
     if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
     if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
