@@ -194,6 +194,29 @@ def test_postprocess_bit_exact_sequence(weights, promo):
     h.close()
 
 
+@pytest.mark.parametrize("promo", [0, 1])
+def test_postprocess_long_filter_chain(weights, promo):
+    """The OneEuro state is a recurrence: 150 frames of moving peaks (a drifting mixture of 5 map sets, so every joint's
+    arg-max wanders and the read-off crosses cell borders), irregular frame times, and a timestamp 0.0 ("no timestamp",
+    OneEuroFilter.py:65) in the middle -- still bit-exact against the oracle on every frame, no drift."""
+    import oracle
+    from tests import helpers
+    scales = [1.0, 0.7]
+    h = _handle(scales, weights, numpy_promotion=promo)
+    ref = oracle.OracleEstimator(scales=scales, nep50=bool(promo))
+    base = [helpers.synth_maps(700 + k, 2) for k in range(5)]
+    t = T0
+    for k in range(150):
+        w = 0.5 + 0.5 * np.sin(0.13 * k + np.arange(5))
+        maps = sum(float(wi) * b for wi, b in zip(w, base)).astype(np.float32)
+        t += 1 / 30 + 0.004 * ((k * 7) % 5)
+        t2d = 0.0 if k == 70 else t
+        a2, a3 = h.postprocess(maps, t2d, t + 0.0004, 1.0, 0, 0)
+        r2, r3 = ref.postprocess(maps, t2d, t + 0.0004, 1.0, 0, 0)
+        assert np.array_equal(a2, r2) and np.array_equal(a3, r3), k
+    h.close()
+
+
 @pytest.mark.parametrize("case", ["pic_default", "wide_default", "square_baseline", "square_one_scale"])
 def test_postprocess_reproduces_reference_recordings(weights, case):
     """The device pre+post-processing reproduces what the reference's own Python returned (fixtures F3)."""
