@@ -93,8 +93,8 @@ def main():
             sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
         h = _native.Handle(SCALES, device=local_rank, num_frame_slots=8, pyramid=(rank, world), precision=prec)
     else:
-        # lanes=2: the second lane only ever runs a frame submitted while another is in flight (the pipelined leg below)
-        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec, lanes=2)
+        # lanes=3: the extra lanes only ever run frames submitted while others are in flight (the pipelined leg below)
+        h = _native.Handle(SCALES, device=local_rank, use_graph=not args.no_graph, num_frame_slots=8, precision=prec, lanes=3)
     h.set_weights(weights)
     h.finalize()
     if args.pyramid:  # rank 0 makes the ncclUniqueId, torch.distributed carries it to the others
@@ -130,17 +130,19 @@ def main():
     elapsed = grp.max_over_ranks(elapsed)
     assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
 
-    # two-deep pipelined rate of the same stream (submit k+1 before collecting k; the frames overlap on two lanes, only the
-    # filter kernels stay ordered), reported beside the synchronous one
+    # pipelined rate of the same stream (three frames in flight on three lanes: they overlap, only the filter kernels stay
+    # ordered), reported beside the synchronous one
     pipelined = None
     if not args.no_aux:
         barrier()
         p0 = time.perf_counter()
-        h.submit_resident(0, t + 1, t + 1 + 1e-3)
-        for i in range(1, args.steps):
+        depth = 3  # frames in flight = lanes of the handle
+        for i in range(args.steps):
+            if i >= depth:
+                h.collect()
             h.submit_resident(i % nslots, t + 1 + i / 30, t + 1 + i / 30 + 1e-3)
+        for _ in range(min(depth, args.steps)):
             h.collect()
-        h.collect()
         torch.cuda.synchronize()
         pipelined = args.steps / (time.perf_counter() - p0)
     t += 1 + args.steps / 30 + 1

@@ -60,11 +60,12 @@ typedef struct vnect_config {
                                          live set, so weights + activations stay in the Infinity Cache between
                                          frames; 1 = one private buffer per layer output, which is what
                                          vnect_read_activation needs to return an inner layer (tests, debugging) */
-    int32_t lanes;                    /* 0/1 (default): frames run one after the other.  2: a frame submitted while another
-                                         is in flight (vnect_submit_resident before vnect_collect) runs on a second lane --
-                                         own stream, activation arena and graph, same weights -- and overlaps with it; only
-                                         the joints kernels stay in order (the OneEuro filters are a chain).  Results are
-                                         bit-identical to sequential execution; costs one more activation arena (~0.1 GB) */
+    int32_t lanes;                    /* 0/1 (default): frames run one after the other.  2 or 3: a frame submitted while others
+                                         are in flight (vnect_submit_resident before vnect_collect; up to `lanes` frames)
+                                         runs on a lane of its own -- own stream, activation arena and graph, same weights --
+                                         and overlaps with them; only the joints kernels stay in order (the OneEuro filters
+                                         are a chain).  Results are bit-identical to sequential execution; each extra lane
+                                         costs one more activation arena (~0.1 GB)                                          */
 } vnect_config;
 
 /* Replaces VNectEstimator.__init__ (src/estimator.py:27-68): session + graph + 42 + 63 filters. */

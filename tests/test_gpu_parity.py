@@ -294,7 +294,7 @@ def test_end_to_end_vs_oracle(h3, ref3, oracle_net):
     print("worst 3-D excess over tolerance:", worst3)
 
 
-@pytest.mark.parametrize("lanes,graph", [(1, True), (2, True), (2, False)])
+@pytest.mark.parametrize("lanes,graph", [(1, True), (2, True), (2, False), (3, True)])
 def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
     """Two frames in flight (submit k+1 before collecting k) return exactly what one-at-a-time inference returns: on one
     lane (same stream), and on two lanes (lanes=2: the frames overlap on two streams / activation arenas and only the
@@ -310,12 +310,16 @@ def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
         b.upload_frame(k, f)
     n = 12
     seq = [b.infer_resident(k % 4, T0 + k / 30, T0 + k / 30 + 0.001) for k in range(n)]
-    a.submit_resident(0, T0, T0 + 0.001)
+    depth = max(lanes, 2)  # frames kept in flight
     got = []
-    for k in range(1, n):
+    for k in range(n):
+        if k >= depth:
+            got.append(a.collect())
         a.submit_resident(k % 4, T0 + k / 30, T0 + k / 30 + 0.001)
+    for _ in range(depth):
         got.append(a.collect())
-    got.append(a.collect())
+    with pytest.raises(_native().VnectError):
+        a.collect()  # nothing left in flight
     for k, ((g2, g3), (s2, s3)) in enumerate(zip(got, seq)):
         assert np.array_equal(g2, s2) and np.array_equal(g3, s3), k  # bit for bit
     # back to one at a time on the same handle: the filter chain continues across the mode change

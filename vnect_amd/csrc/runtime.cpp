@@ -76,11 +76,12 @@ struct vnect_handle {
     bool keep_activations = true;  // one private buffer per layer output (vnect_read_activation needs it); false = arena
     size_t arena_bytes = 0;
     std::vector<size_t> arena_off;  // byte offset of every tensor in the arena
-    // Second lane (cfg.lanes == 2): a frame submitted while another is in flight runs on `twin` -- its own stream, activation
+    // More lanes (cfg.lanes == 2, 3): a frame submitted while others are in flight runs on a twin -- its own stream, activation
     // arena, split-K workspace, arg-max scratch and graph; weights, tables, resident frames, the result ring and the filter
     // bank are this handle's.  The two frames overlap everywhere except in the joints kernel (the filters are a chain).
-    vnect_handle* twin = nullptr;
+    std::vector<vnect_handle*> twins;  // lanes 1 .. cfg.lanes-1 (lane 0 is this handle)
     bool is_twin = false;
+    long long lane_seq = -1;           // sequence number of the last frame submitted on this lane
     vnect_handle* last_lane = nullptr;  // lane of the most recently submitted frame
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
@@ -1004,29 +1005,28 @@ int build_graph(vnect_handle* h)
     return VNECT_OK;
 }
 
-void destroy_twin(vnect_handle* h)
+void destroy_twins(vnect_handle* h)
 {
-    vnect_handle* t = h->twin;
-    if (!t) return;
-    if (t->st) hipStreamSynchronize(t->st);
-    if (t->gexec) hipGraphExecDestroy(t->gexec);
-    if (t->graph) hipGraphDestroy(t->graph);
-    for (int i = 0; i < RING; i++)
-        if (t->h_fp[i]) hipHostFree(t->h_fp[i]);
-    for (void* p : t->dev_allocs) hipFree(p);
-    if (t->st) hipStreamDestroy(t->st);
-    delete t;
-    h->twin = nullptr;
+    for (vnect_handle* t : h->twins) {
+        if (t->st) hipStreamSynchronize(t->st);
+        if (t->gexec) hipGraphExecDestroy(t->gexec);
+        if (t->graph) hipGraphDestroy(t->graph);
+        for (int i = 0; i < RING; i++)
+            if (t->h_fp[i]) hipHostFree(t->h_fp[i]);
+        for (void* p : t->dev_allocs) hipFree(p);
+        if (t->st) hipStreamDestroy(t->st);
+        delete t;
+    }
+    h->twins.clear();
+    h->last_lane = nullptr;
 }
 
-// The second lane of a two-deep pipeline (vnect_config::lanes == 2): same layers and weights, its own stream, activation
-// arena, workspace, arg-max scratch, geometry block and graph.
+// One more lane of the frame pipeline (vnect_config::lanes): same layers and weights, its own stream, activation arena,
+// workspace, arg-max scratch, geometry block and graph.
 int build_twin(vnect_handle* h)
 {
-    destroy_twin(h);
-    if (h->cfg.lanes != 2 || h->sharded || h->keep_activations) return VNECT_OK;
     vnect_handle* t = new vnect_handle();
-    h->twin = t;
+    h->twins.push_back(t);
     t->is_twin = true;
     t->cfg = h->cfg, t->S = h->S, t->Snet = h->Snet, t->bf16 = h->bf16, t->keep_activations = false;
     HIPCK(h, hipStreamCreateWithFlags(&t->st, hipStreamNonBlocking));
@@ -1053,12 +1053,24 @@ int build_twin(vnect_handle* h)
     return VNECT_OK;
 }
 
+int build_twins(vnect_handle* h)
+{
+    destroy_twins(h);
+    if (h->cfg.lanes < 2 || h->sharded || h->keep_activations) return VNECT_OK;
+    for (int i = 1; i < h->cfg.lanes; i++) {
+        int rc = build_twin(h);
+        if (rc) return rc;
+    }
+    return VNECT_OK;
+}
+
 // enqueue one frame from a resident slot; results land in h_out[ring]
 int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_out)
 {
     if (slot < 0 || slot >= (int)h->slots.size() || h->slots[slot].H == 0)
         return fail(h, VNECT_E_ARG, "frame slot empty or out of range");
-    if (h->seq_submit - h->seq_collect >= 2) return fail(h, VNECT_E_STATE, "two frames already in flight");
+    const unsigned long long max_in_flight = h->twins.empty() ? 2 : h->twins.size() + 1;  // one lane: two frames queue on its stream
+    if (h->seq_submit - h->seq_collect >= max_in_flight) return fail(h, VNECT_E_STATE, "too many frames in flight: collect one first");
     if (h->sharded && !h->comm)  // refuse before any filter / timestamp state changes
         return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init before inference");
     const auto& si = h->slots[slot];
@@ -1073,10 +1085,15 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     dyn.row_stride = si.stride;
     dyn.frame = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
     const bool timed = h->profiling;
-    // Lane: the first one, unless a frame is still in flight there and a second lane exists -- then the two frames overlap
-    // (the idle CUs between one frame's launches are the other frame's), and only the joints kernels stay in order.
+    // Lane: the first whose last frame has been collected (lane 0 when nothing is in flight).  Frames on different lanes
+    // overlap -- the idle CUs between one frame's launches are the other frames' -- and only the joints kernels stay in order.
     vnect_handle* L = h;
-    if (h->twin && !timed && h->seq_submit != h->seq_collect && h->last_lane == h) L = h->twin;
+    if (!h->twins.empty() && !timed && h->lane_seq >= (long long)h->seq_collect)
+        for (vnect_handle* t : h->twins)
+            if (t->lane_seq < (long long)h->seq_collect) {
+                L = t;
+                break;
+            }
     if ((rc = sync_geometry(L, fp))) return fail(h, rc, L->err);
     if (timed) HIPCK(h, hipEventRecord(h->ev[0], L->st));
     if ((rc = run_pre(L, dyn))) return fail(h, rc, L->err);
@@ -1094,6 +1111,7 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     if (timed) HIPCK(h, hipEventRecord(h->ev[3], L->st));
     HIPCK(h, hipEventRecord(h->done[ring], L->st));
     h->last_lane = L;
+    L->lane_seq = (long long)h->seq_submit;
     h->slots[slot].last_use = (long long)h->seq_submit;
     h->seq_submit++;
     *ring_out = ring;
@@ -1201,6 +1219,8 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         return fail(nullptr, VNECT_E_ARG, "vnect_create: num_scales out of range");
     if (cfg->precision != VNECT_FP32 && cfg->precision != VNECT_BF16)
         return fail(nullptr, VNECT_E_ARG, "vnect_create: precision must be VNECT_FP32 or VNECT_BF16");
+    if (cfg->lanes < 0 || cfg->lanes > RING - 1)
+        return fail(nullptr, VNECT_E_ARG, "vnect_create: lanes must be 0 .. 3");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
         return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: no HIP device " + std::to_string(cfg->device));
@@ -1260,7 +1280,7 @@ void vnect_destroy(vnect_handle* h)
     if (!h) return;
     hipSetDevice(h->cfg.device);
     if (h->st) hipStreamSynchronize(h->st);
-    destroy_twin(h);
+    destroy_twins(h);
     if (h->comm && p_ncclCommDestroy) p_ncclCommDestroy(h->comm);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     if (h->graph) hipGraphDestroy(h->graph);
@@ -1310,7 +1330,7 @@ int vnect_finalize(vnect_handle* h)
     }
     rc = build_graph(h);
     if (rc) return rc;
-    rc = build_twin(h);
+    rc = build_twins(h);
     if (rc) return rc;
     HIPCK(h, hipStreamSynchronize(h->st));
     h->finalized = true;
@@ -1325,7 +1345,7 @@ int vnect_set_scales(vnect_handle* h, const double* scales, int n)
     if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
     HIPCK(h, hipSetDevice(h->cfg.device));
     HIPCK(h, hipStreamSynchronize(h->st));
-    if (h->twin) HIPCK(h, hipStreamSynchronize(h->twin->st));
+    for (vnect_handle* t : h->twins) HIPCK(h, hipStreamSynchronize(t->st));
     double old[VNECT_MAX_SCALES];
     memcpy(old, h->cfg.scales, sizeof old);
     for (int i = 0; i < n; i++) h->cfg.scales[i] = scales[i];
