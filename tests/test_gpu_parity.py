@@ -330,6 +330,42 @@ def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
     a.close(), b.close()
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_soak_three_lanes_deterministic(weights, prec):
+    """Race detector: 3 000 frames of one stream, three in flight on three lanes, twice, and once frame by frame -- all
+    three result sequences must be identical bit for bit (the K-group hand-off through LDS, the lane events, the result
+    ring and the arena sharing all have to be right every single time for that)."""
+    from tests import helpers
+    frames = [helpers.synth_frame(40 + k, smooth=(k % 2 == 0)) for k in range(8)]
+    h = _handle(BASELINE_SCALES, weights, lanes=3, num_frame_slots=8,
+                precision=_native().BF16 if prec == "bf16" else _native().FP32)
+    for k, f in enumerate(frames):
+        h.upload_frame(k, f)
+    n = 3000
+
+    def run(depth):
+        h.reset_filters()
+        out = np.empty((n, 21, 5), np.float64)
+        got = 0
+        for k in range(n):
+            if k >= depth:
+                j2, j3 = h.collect()
+                out[got, :, :2], out[got, :, 2:] = j2, j3
+                got += 1
+            h.submit_resident((k * 3) % 8, T0 + k / 30, T0 + k / 30 + 0.0005)
+        while got < n:
+            j2, j3 = h.collect()
+            out[got, :, :2], out[got, :, 2:] = j2, j3
+            got += 1
+        return out
+
+    a, b, c = run(3), run(3), run(1)
+    h.close()
+    assert np.all(np.isfinite(a))
+    assert np.array_equal(a, b), "two pipelined runs differ at frame %d" % int(np.argmax(np.any(a != b, axis=(1, 2))))
+    assert np.array_equal(a, c), "pipelined and frame-by-frame runs differ at frame %d" % int(np.argmax(np.any(a != c, axis=(1, 2))))
+
+
 def test_estimator_submit_collect_two_lanes(weights):
     """The facade's additive pipelined API (submit / collect, lanes=2) against its own frame-by-frame __call__, with frames
     uploaded from host memory each time (an upload waits only for the inference that still reads its slot)."""
