@@ -63,7 +63,7 @@ __device__ __forceinline__ void bload_lds(srd_t, float*, unsigned, unsigned) {}
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
-// Streaming variant (64x64 tiles): a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
+// The conv kernel.  Streaming: a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
 // chunks as one stream through the LDS ring.  The producers simply keep issuing -- the first chunks of the next
 // tile land while the consumers are still in the previous tile's epilogue -- so the per-tile fixed cost (wave
 // launch, argument fetch, first-load latency, store drain: ~5 us, more than the K loop of the 1x1 layers) is paid
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         // chunk costs 4 DMA instructions and a few scalar adds -- no vector address arithmetic, no zero-page select.
         // Padded taps and rows past M use the buffer bounds check: such a lane's offset is 2^31 (>= num_records), the
         // hardware fetches nothing and writes zeros.  Negative tap offsets are folded into the descriptor's base
-        // (in - tap_bias), so the scalar offset toff[] is >= 0 (runtime.cpp).
+        // (in - tap_bias), so the scalar offset is >= 0 (runtime.cpp).
         __builtin_amdgcn_s_setprio(3);
         struct Prod {
             const float *in, *w;
@@ -645,7 +645,7 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
 {
     const int epr = a.bf16 ? 64 : 32;
     if (a.Npad % BN != 0 || a.K != a.ntaps * a.cpt * epr || a.nphase * a.ntaps > MAX_TAPS ||
-        a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || !a.zeros || (a.bf16 && a.out2 && a.split_n % 64))
+        a.ksplit < 1 || (a.ksplit > 1 && !a.ws) || (a.Cs & 3) || (a.bf16 && a.out2 && a.split_n % 64))
         return hipErrorInvalidValue;
     // range of the multiply-high divisions in the kernel (x / d exact while x * d < 2^32)
     if ((long long)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1ll << 32) || a.M >= (1 << 24)) return hipErrorInvalidValue;

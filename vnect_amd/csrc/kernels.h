@@ -30,7 +30,6 @@ struct ConvArgs {
     unsigned long long* prof;  // nullptr, or {min start, ...} of this launch in 100 MHz s_memrealtime ticks
     unsigned long long* prof_end;  // profiling twin: [PROF_WGS] end stamp of every workgroup (plain stores: an atomic max
                                    // over 500 workgroups put ~1.4 us behind every launch); the host takes the maximum
-    const float* zeros;   // >= 128 B of zeros (source of padded taps / rows past M for the LDS-DMA loads)
     int S, H, W, Cs;      // input grid, floats per input pixel
     int Ho, Wo, M;        // logical output grid, M = S*Ho*Wo
     int K, ntaps, cpt;    // K = ntaps*cpt*32

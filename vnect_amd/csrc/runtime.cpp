@@ -69,7 +69,6 @@ struct vnect_handle {
     float* in3 = nullptr;  // (S,368,368,3) staging for vnect_forward / preprocess read-back
     float* ws = nullptr;
     size_t ws_floats = 0;
-    float* zeros = nullptr;
     std::vector<void*> dev_allocs;
     char* param_cur = nullptr;     // bump allocator over large blocks for packed weights / biases (param_alloc)
     size_t param_left = 0;
@@ -558,7 +557,7 @@ void bind_activations(vnect_handle* h, Layer& L)
     a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
     a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
     a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
-    a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws, a.zeros = h->zeros;
+    a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws;
     L.r.ws = h->ws, L.r.resid = a.resid, L.r.out = a.out;
 }
 
@@ -794,11 +793,6 @@ int finalize_impl(vnect_handle* h)
         int rc = dev_alloc(h, &h->ws, ws);
         if (rc) return rc;
     }
-    {
-        int rc = dev_alloc(h, &h->zeros, 256);
-        if (rc) return rc;
-        HIPCK(h, hipMemset(h->zeros, 0, 256 * sizeof(float)));
-    }
     HIPCK(h, hipDeviceSynchronize());
     h->conv_flops = 0, h->conv_launches = 0;
     for (Layer& L : h->layers) {
@@ -1031,7 +1025,7 @@ int build_twin(vnect_handle* h)
     t->cfg = h->cfg, t->S = h->S, t->Snet = h->Snet, t->bf16 = h->bf16, t->keep_activations = false;
     HIPCK(h, hipStreamCreateWithFlags(&t->st, hipStreamNonBlocking));
     // shared: read-only tables and frames; the filter bank (its users are chained by events)
-    t->frames = h->frames, t->d_stabs = h->d_stabs, t->d_mtabs = h->d_mtabs, t->d_up = h->d_up, t->d_fb = h->d_fb, t->zeros = h->zeros;
+    t->frames = h->frames, t->d_stabs = h->d_stabs, t->d_mtabs = h->d_mtabs, t->d_up = h->d_up, t->d_fb = h->d_fb;
     t->slots = h->slots;
     int rc;
     if ((rc = dev_alloc(t, &t->d_fp, 1))) return fail(h, rc, t->err);
