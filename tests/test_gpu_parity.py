@@ -194,6 +194,28 @@ def test_postprocess_bit_exact_sequence(weights, promo):
     h.close()
 
 
+def test_four_scales_whole_path(weights, oracle_net):
+    """More than three scales takes the general (8-scale) form of the merge code and a 4-image batch through the conv stack:
+    pre-processing and post-processing bit-exact, final maps and joints within the fp32 tolerances."""
+    import oracle
+    from tests import helpers
+    scales = [1.0, 0.9, 0.75, 0.6]
+    h = _handle(scales, weights)
+    ref = oracle.OracleEstimator(scales=scales, net=oracle_net)
+    frame = helpers.synth_frame(321, 400, 310, smooth=True)
+    b, sc, off = h.preprocess(frame)
+    rb, rs, roff = oracle.gen_input_batch(frame, scales)
+    assert np.array_equal(b, rb) and sc == rs and off == roff
+    maps, rmaps = h.forward(b), oracle_net.forward(rb)
+    assert np.abs(maps - rmaps).max() <= 1e-4 * np.abs(rmaps).max()
+    for k in range(3):
+        t = T0 + k / 30
+        a2, a3 = h.postprocess(rmaps, t, t + 0.0005, sc, off[0], off[1])
+        r2, r3 = ref.postprocess(rmaps, t, t + 0.0005, sc, off[0], off[1])
+        assert np.array_equal(a2, r2) and np.array_equal(a3, r3), k
+    h.close()
+
+
 @pytest.mark.parametrize("promo", [0, 1])
 def test_postprocess_long_filter_chain(weights, promo):
     """The OneEuro state is a recurrence: 150 frames of moving peaks (a drifting mixture of 5 map sets, so every joint's

@@ -100,15 +100,18 @@ hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* 
 // estimator.py:105-129: one cell of a merged map,
 //   avg_q[r][c][j] = (1/S) * sum_i crop(cv2.resize(map_i_q, fx=fy=1/s_i))[r][c][j]   (f32 interpolation, f64 sum)
 // evaluated on demand: the four 46x46x21 f64 averages of the reference are never materialised.
+// SMAX: compile-time bound of the scale loops (3 covers the reference's and BASELINE's pyramids; these kernels run their
+// code once, cold, so its size is their time: the 8-scale form is twice as long)
+template <int SMAX>
 __device__ __forceinline__ double merged_cell(const float* __restrict__ maps, const MergeTabs* __restrict__ tabs, int S,
                                               int ch, int r, int c)
 {
     // All taps of all scales are requested before any is used (no load sits behind a data-dependent branch), so a
     // thread pays one memory round trip, not one per scale.  For a scale that is a plain copy (size unchanged) the
     // tables are the identity: tap (sy0[r], sx[c]) IS element (r, c).
-    float p00[VNECT_MAX_S], p01[VNECT_MAX_S], p10[VNECT_MAX_S], p11[VNECT_MAX_S];
+    float p00[SMAX], p01[SMAX], p10[SMAX], p11[SMAX];
 #pragma unroll
-    for (int i = 0; i < VNECT_MAX_S; i++) {
+    for (int i = 0; i < SMAX; i++) {
         if (i < S) {
             const MergeTab& mt = tabs->t[i];
             const float* M = maps + (long long)i * HM * HM * MAPC + ch;
@@ -120,7 +123,7 @@ __device__ __forceinline__ double merged_cell(const float* __restrict__ maps, co
     }
     double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < VNECT_MAX_S; i++) {
+    for (int i = 0; i < SMAX; i++) {
         if (i < S) {
             const MergeTab& mt = tabs->t[i];
             const float a0 = mt.a0[c], a1 = mt.a1[c];
@@ -153,6 +156,7 @@ __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { ret
 constexpr int ARG_THREADS = 384;  // one thread per column (368 used)
 constexpr int ARG_SEGS = 6;       // 8-row segments per workgroup: 8 slabs x 6 >= 47 segments, 168 workgroups keep the f64 work off one CU
 
+template <int SMAX>
 __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* __restrict__ maps,
                                                                   const MergeTabs* __restrict__ mtabs, int S,
                                                                   const UpTab* __restrict__ up,
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* _
         const int cells = (r_hi - r_lo + 1) * HM;
         for (int p = tid; p < cells; p += ARG_THREADS) {
             const int r = r_lo + p / HM, c = p % HM;
-            map[r * HM + c] = merged_cell(maps, mtabs, S, j, r, c);
+            map[r * HM + c] = merged_cell<SMAX>(maps, mtabs, S, j, r, c);
         }
     }
     __syncthreads();
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* _
 }
 hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st)
 {
-    hipLaunchKernelGGL(heat_argmax_kernel, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part);
+    if (S <= 3) hipLaunchKernelGGL(heat_argmax_kernel<3>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part);
+    else hipLaunchKernelGGL(heat_argmax_kernel<VNECT_MAX_S>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part);
     return hipGetLastError();
 }
 
@@ -286,6 +291,7 @@ __device__ float oef_f32(Filt& f, float x, double t, int nep50)
 }
 
 // utils.hm_pt_interp_bilinear (utils.py:58-79), scale 8, on merged map q (channel ch) evaluated cell by cell
+template <int SMAX>
 __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S, int ch,
                             double dst_y, double dst_x)
 {
@@ -296,8 +302,8 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
     y0 = y0 < 0 ? 0 : (y0 > HM - 1 ? HM - 1 : y0);  // keep NaN inputs from indexing outside the map
     const int x1 = x0 + 1 < HM - 1 ? x0 + 1 : HM - 1;
     const int y1 = y0 + 1 < HM - 1 ? y0 + 1 : HM - 1;
-    const double m00 = merged_cell(maps, mtabs, S, ch, y0, x0), m01 = merged_cell(maps, mtabs, S, ch, y0, x1);
-    const double m10 = merged_cell(maps, mtabs, S, ch, y1, x0), m11 = merged_cell(maps, mtabs, S, ch, y1, x1);
+    const double m00 = merged_cell<SMAX>(maps, mtabs, S, ch, y0, x0), m01 = merged_cell<SMAX>(maps, mtabs, S, ch, y0, x1);
+    const double m10 = merged_cell<SMAX>(maps, mtabs, S, ch, y1, x0), m11 = merged_cell<SMAX>(maps, mtabs, S, ch, y1, x1);
     const double v0 = (x1 - src_x) * m00 + (src_x - x0) * m01;
     const double v1 = (x1 - src_x) * m10 + (src_x - x0) * m11;
     return (y1 - src_y) * v0 + (src_y - y0) * v1;
@@ -305,6 +311,7 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
 
 // estimator.py:132-139 for all 21 joints in one workgroup, one thread per filter: 42 2-D filters, then 63 read-offs
 // (x/y/z maps merged on demand) + root subtraction + 63 3-D filters, then the un-mapping.
+template <int SMAX>
 __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
                                                      const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
                                                      const FrameParams* __restrict__ fp, const FrameDyn dyn, int nep50,
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
         fb->f2[j2][k2] = f2;
     }
     __syncthreads();
-    if (t < NJ * 3) p3[t] = (float)(pt_interp(maps, &smt, S, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
+    if (t < NJ * 3) p3[t] = (float)(pt_interp<SMAX>(maps, &smt, S, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
     __syncthreads();
     if (t < NJ * 3) {
         const float v = p3[t] - p3[14 * 3 + k3];  // joints_3d -= joints_3d[14, :] in float32
@@ -352,7 +359,8 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
 hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
                          const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(joints_kernel, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+    if (S <= 3) hipLaunchKernelGGL(joints_kernel<3>, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+    else hipLaunchKernelGGL(joints_kernel<VNECT_MAX_S>, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, dyn, nep50, out);
     return hipGetLastError();
 }
 
