@@ -94,13 +94,13 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    {   // The ~400-byte argument block spans seven scalar-cache lines and the compiler loads fields where they are first
+    {   // The 280-byte argument block spans five scalar-cache lines and the compiler loads fields where they are first
         // used, one scalar-cache round trip after another (cold: 1.7 us from wave start to the first LDS-DMA): touch every line now
         typedef __attribute__((address_space(4))) const int kint;
         kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
-        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80], k6 = kp[96];
-        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6));
-        static_assert(sizeof(ConvArgs) <= 448 && sizeof(ConvArgs) > 384, "touch every 64-byte line of the argument block");
+        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64];
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4));
+        static_assert(sizeof(ConvArgs) <= 320 && sizeof(ConvArgs) > 256, "touch every 64-byte line of the argument block");
     }
     // Fields are pinned in SGPRs in three groups -- common, producer-only, consumer-only (the branch is wave-uniform, so
     // each path holds only its own) -- and each group is fetched as a few wide scalar loads with ONE wait.  Left to the

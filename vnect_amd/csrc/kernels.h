@@ -49,12 +49,11 @@ struct ConvArgs {
     unsigned mg_ks, mg_cpt;  // same for d = ksplit, cpt
     unsigned mg_wo, mg_ho, mg_tn, mg_tm;  // ceil(2^32 / d) for d = Wo, Ho, tiles_n, tiles_m (launcher): x / d == umulhi(x, mg) for x*d < 2^32
     long long w_phase_stride;
-    int dy[MAX_TAPS], dx[MAX_TAPS];  // [phase*ntaps + tap]; 32-bit so the (uniform) lookups are scalar loads
     // streaming kernel (buffer-addressed LDS-DMA): the byte offset of a tap from the lane's input pixel is
     // (dy*W + dx)*Cs*esz + tap_bias with tap_bias = -min over taps (so it is >= 0; the descriptor's base is in - tap_bias)
     int tap_bias;
-    // the same tap table as 4-bit fields (value + 8, entry [phase*ntaps + tap] at bits 4*entry): the streaming kernel's
-    // producers decode dy / dx with scalar shifts instead of one dependent scalar load per tap
+    // filter taps (dy, dx) as 4-bit fields (value + 8, entry [phase*ntaps + tap] at bits 4*entry): the producers decode them
+    // with scalar shifts -- no table in the argument block, no dependent scalar load per tap
     unsigned long long dy_pack, dx_pack;
     int tapgrid;  // 1: single tap (0,0); 3: the 3x3 grid with pad 1 (validity masks in closed form); 0: walk the table
 };

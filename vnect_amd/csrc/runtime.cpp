@@ -43,6 +43,7 @@ struct Layer {
     ConvArgs a{};
     ReduceArgs r{};
     int BM = 64, BN = 64, KG = 1;  // tile shape; KG = in-workgroup K groups (conv.hip)
+    int dy[MAX_TAPS] = {}, dx[MAX_TAPS] = {};  // filter taps [phase*ntaps + tap] (host side; the kernel gets them packed)
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     int Nreal = 0, Kreal = 0;
     double flops = 0;
@@ -469,7 +470,7 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
         // Pixel 7, channel 3 (and row 7 in bf16) carry zero weights.
         a.pixmode = 1, a.cpt = 1, cp = 32;
         a.ntaps = h->bf16 ? 4 : 7;
-        for (int t = 0; t < a.ntaps; t++) a.dy[t] = (int)((h->bf16 ? 2 * t : t) - pt), a.dx[t] = (int)(-pl);
+        for (int t = 0; t < a.ntaps; t++) L.dy[t] = (int)((h->bf16 ? 2 * t : t) - pt), L.dx[t] = (int)(-pl);
     } else {
         cp = round_up(tin.Cs, EPR);
         if (cp != tin.Cs) {
@@ -478,7 +479,7 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
         }
         a.pixmode = 0, a.ntaps = sp.k * sp.k, a.cpt = cp / EPR;
         for (int ky = 0; ky < sp.k; ky++)
-            for (int kx = 0; kx < sp.k; kx++) a.dy[ky * sp.k + kx] = (int)(ky - pt), a.dx[ky * sp.k + kx] = (int)(kx - pl);
+            for (int kx = 0; kx < sp.k; kx++) L.dy[ky * sp.k + kx] = (int)(ky - pt), L.dx[ky * sp.k + kx] = (int)(kx - pl);
     }
     a.K = a.ntaps * a.cpt * EPR;
     L.Kreal = sp.k * sp.k * cin;
@@ -687,7 +688,7 @@ int finalize_impl(vnect_handle* h)
                 for (int ta = 0; ta < 2; ta++)
                     for (int tb = 0; tb < 2; tb++) {
                         const int t = ta * 2 + tb, ky = kys[py][ta], kx = kys[px][tb];
-                        a.dy[z * 4 + t] = (int)dys[py][ta], a.dx[z * 4 + t] = (int)dys[px][tb];
+                        L.dy[z * 4 + t] = (int)dys[py][ta], L.dx[z * 4 + t] = (int)dys[px][tb];
                         for (int n = 0; n < 191; n++) {
                             const float* src = n < 128 ? &W2->d[(((size_t)ky * 4 + kx) * 128 + n) * 256]
                                                        : &W1->d[(((size_t)ky * 4 + kx) * 63 + (n - 128)) * 256];
@@ -802,22 +803,22 @@ int finalize_impl(vnect_handle* h)
         {   // tap byte offsets for the buffer-addressed loads (kernels.h)
             const int esz = a.bf16 ? 2 : 4, nt = a.nphase * a.ntaps;
             int lo = 0;
-            for (int t = 0; t < nt; t++) lo = std::min(lo, (a.dy[t] * a.W + a.dx[t]) * a.Cs * esz);
+            for (int t = 0; t < nt; t++) lo = std::min(lo, (L.dy[t] * a.W + L.dx[t]) * a.Cs * esz);
             a.tap_bias = -lo;
             a.tapgrid = 0;
-            if (a.nphase == 1 && a.ntaps == 1 && a.dy[0] == 0 && a.dx[0] == 0 && !a.pixmode) a.tapgrid = 1;
+            if (a.nphase == 1 && a.ntaps == 1 && L.dy[0] == 0 && L.dx[0] == 0 && !a.pixmode) a.tapgrid = 1;
             if (a.nphase == 1 && a.ntaps == 9 && !a.pixmode) {
                 bool ok = true;
-                for (int t = 0; t < 9; t++) ok = ok && a.dy[t] == t / 3 - 1 && a.dx[t] == t % 3 - 1;
+                for (int t = 0; t < 9; t++) ok = ok && L.dy[t] == t / 3 - 1 && L.dx[t] == t % 3 - 1;
                 if (ok) a.tapgrid = 3;
             }
             a.dy_pack = a.dx_pack = 0;
             for (int t = 0; t < nt; t++) {
-                if (a.dy[t] < -8 || a.dy[t] > 7 || a.dx[t] < -8 || a.dx[t] > 7) {
+                if (L.dy[t] < -8 || L.dy[t] > 7 || L.dx[t] < -8 || L.dx[t] > 7) {
                     h->err = "internal: filter tap outside the packed range";
                     return VNECT_E_ARG;
                 }
-                a.dy_pack |= (unsigned long long)(a.dy[t] + 8) << (4 * t), a.dx_pack |= (unsigned long long)(a.dx[t] + 8) << (4 * t);
+                a.dy_pack |= (unsigned long long)(L.dy[t] + 8) << (4 * t), a.dx_pack |= (unsigned long long)(L.dx[t] + 8) << (4 * t);
             }
         }
         if (a.ksplit > 1) {
