@@ -195,18 +195,30 @@ class Handle:
         H, W = img.shape[:2]
         self._ck(lib().vnect_upload_frame(self._h, slot, _ptr(img, _u8p), H, W, img.strides[0]))
 
+    # The per-frame calls sit between two frames of a synchronous stream (the GPU idles meanwhile): they hand the library
+    # one pair of result buffers whose ctypes pointers are made once, and return fresh copies as the reference does.
+    def _results(self):
+        if getattr(self, "_res", None) is None:
+            j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
+            self._res = (j2, j3, _ptr(j2, _f64p), _ptr(j3, _f32p), lib().vnect_infer_resident, lib().vnect_collect)
+        return self._res
+
     def infer_resident(self, slot, t2d, t3d):
-        j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
-        self._ck(lib().vnect_infer_resident(self._h, slot, t2d, t3d, _ptr(j2, _f64p), _ptr(j3, _f32p)))
-        return j2, j3
+        j2, j3, p2, p3, fn, _ = self._results()
+        rc = fn(self._h, slot, t2d, t3d, p2, p3)
+        if rc:
+            self._ck(rc)
+        return j2.copy(), j3.copy()
 
     def submit_resident(self, slot, t2d, t3d):
         self._ck(lib().vnect_submit_resident(self._h, slot, t2d, t3d))
 
     def collect(self):
-        j2, j3 = np.empty((21, 2), np.float64), np.empty((21, 3), np.float32)
-        self._ck(lib().vnect_collect(self._h, _ptr(j2, _f64p), _ptr(j3, _f32p)))
-        return j2, j3
+        j2, j3, p2, p3, _, fn = self._results()
+        rc = fn(self._h, p2, p3)
+        if rc:
+            self._ck(rc)
+        return j2.copy(), j3.copy()
 
     @staticmethod
     def comm_unique_id():
