@@ -241,13 +241,16 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             set_tap(tap);
         };
         auto issue = [&](int stage) __attribute__((always_inline)) {
-            float* sb = smem + stage * STAGE + wave * (8 * 32);  // wave-uniform; the hardware adds lane * 16 B
+            // stage base and scalar offsets are wave-uniform: say so at the use (if register pressure ever pushes this state
+            // machine into VGPRs -- the PROF = 2 build did -- each DMA would otherwise be wrapped in a readfirstlane waterfall loop)
+            float* sb = smem + __builtin_amdgcn_readfirstlane(stage) * STAGE + wave * (8 * 32);  // the hardware adds lane * 16 B
+            const unsigned uA = (unsigned)__builtin_amdgcn_readfirstlane((int)soA), uB = (unsigned)__builtin_amdgcn_readfirstlane((int)soB);
 #pragma unroll
             for (int k = 0; k < KG; k++) {  // K group k: the k-th 128-byte run of the step, landed in its own image
 #pragma unroll
-                for (int i = 0; i < ARB; i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], soA + k * 128);
+                for (int i = 0; i < ARB; i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
 #pragma unroll
-                for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], soB + k * 128);
+                for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], uB + k * 128);
             }
             rem = __builtin_amdgcn_readfirstlane(rem - 1);
             if (rem == 0) {
@@ -289,21 +292,21 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         __builtin_amdgcn_s_barrier();  // chunk 0 visible
         if (G > 2) put();
         const bool pacct = P2 && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
-        long long pw = 0, pb = 0, pi = 0;
+        unsigned pw = 0, pb = 0, pi = 0;  // 32-bit cycle counts (differences of the low halves of s_memtime): the tuning twin is short of SGPRs
         // one barrier per chunk, also after the last one (keeps the consumer loop branch-free).  Steady state: chunk g+1
         // complete in LDS, chunks g+2 .. g+NS-2 still in flight, chunk g+NS-1 issued behind the barrier that retires
         // stage g-1.
         for (; g < G; g++) {
-            const long long q0 = P2 ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned q0 = P2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
             const int young = nis - g - 2;  // chunks allowed to be still in flight once chunk g+1 has landed
             if (young == NS - 3) wait_vm<(NS - 3) * NLD>();
             else wait_landed(young > 0 ? young : 0);
-            const long long q1 = P2 ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned q1 = P2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
             __builtin_amdgcn_s_barrier();  // consumers are past chunk g-1: its stage may be refilled
-            const long long q2 = P2 ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned q2 = P2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
             const int target = G < g + NS ? G : g + NS;
             while (nis < target) put();
-            const long long q3 = P2 ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned q3 = P2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
             pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
         }
         if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         }
     };
     int stage = 0;
-    long long cbw = 0;  // profiling twin: cycles consumer wave 0 waits at the per-chunk barrier
+    unsigned cbw = 0;  // tuning twin: cycles consumer wave 0 waits at the per-chunk barrier
     // One chunk = 16 dependent MFMAs (fp32).  The chunk opens with the barrier that publishes chunk g+1 (and tells the
     // producers this wave is past chunk g-1: its operands of chunk g are already in registers); the 8 fragment reads of
     // chunk g+1 then go out behind every second MFMA.  A wave issues in order, so a read that has to queue at the LDS
@@ -344,9 +347,9 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
         if constexpr (P2) {
-            const long long b0 = __builtin_amdgcn_s_memtime();
+            const unsigned b0 = (unsigned)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
-            cbw += __builtin_amdgcn_s_memtime() - b0;
+            cbw += (unsigned)__builtin_amdgcn_s_memtime() - b0;
         } else
             __builtin_amdgcn_s_barrier();  // chunk g+1 visible; every consumer is past chunk g-1
         if constexpr (!BF) {
