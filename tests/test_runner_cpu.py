@@ -18,6 +18,9 @@ class FakeEstimator:
         self.crops.append(img.shape)
         return self.j2.copy(), np.zeros((21, 3), np.float32)
 
+    def reset(self):
+        self.resets = getattr(self, "resets", 0) + 1
+
 
 def test_bbox_update_matches_reference_arithmetic():
     j2 = np.zeros((21, 2))
@@ -59,3 +62,20 @@ def test_track_loop_updates_crop():
     # different streams are different videos, same stream is reproducible
     a = next(runner.synthetic_stream(1, 1)); b = next(runner.synthetic_stream(2, 1)); c = next(runner.synthetic_stream(1, 1))
     assert not np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_init_box_probes_the_whole_frame_then_resets():
+    """the box initialiser = full-frame pass (the reference's no-detection rectangle, hog_box.py:28-29)
+    + the loop's box arithmetic; the probe must not leave filter state behind."""
+    frame = next(runner.synthetic_stream(3, 1, 240, 320))
+    j2 = np.zeros((21, 2))
+    j2[:, 0] = np.linspace(40, 200, 21)
+    j2[:, 1] = np.linspace(100, 180, 21)
+    est = FakeEstimator(j2)
+    rect = runner.init_box(est, frame, timestamp=5.0)
+    assert est.crops == [(240, 320, 3)] and est.resets == 1
+    assert rect == runner.bbox_update(j2, 320, 240)
+    # all joints on one pixel -> degenerate box -> whole frame
+    est2 = FakeEstimator(np.full((21, 2), 7.0))
+    x, y, w, h = runner.bbox_update(est2.j2, 320, 240)
+    assert runner.init_box(est2, frame) == ([x, y, w, h] if w >= 1 and h >= 1 else [0, 0, 320, 240])

@@ -5,7 +5,9 @@
   2-D joints back by the crop origin.
 * ``track``     -- the frame loop of ``run_estimator_ps.py:80-109``: crop -> estimator -> bounding-box update from
   the joints, for any iterable of frames (synthetic streams on the GPU box; there is no camera / ffmpeg).
-The capture, HOG initialiser, drawing and 3-D plotting of the reference stay out of scope.
+* ``init_box``  -- the person-box initialiser: the reference's HOG detector (``src/hog_box.py``) replaced by one pass of
+  the network over the whole frame and the loop's own box arithmetic.
+The capture, drawing and 3-D plotting of the reference stay out of scope.
 """
 import numpy as np
 
@@ -44,6 +46,24 @@ def bbox_update(joints_2d, W_img, H_img):
             max(int(y_min - buffer_y / 2), 0))
     w, h = (int(min(x_max - x_min + buffer_x, W_img - x)),
             int(min(y_max - y_min + buffer_y, H_img - y)))
+    return [x, y, w, h]
+
+
+def init_box(estimator, frame, timestamp=None):
+    """Person-box initialiser without cv2's HOG detector (SURVEY 8 f-row 3; the reference: src/hog_box.py:25-58).
+
+    The reference asks a HOG people detector for a rectangle and falls back to the whole frame when it finds nobody
+    (hog_box.py:28-29).  Here the network itself proposes the box: one pass over the whole frame (that fallback
+    rectangle), then the tracking loop's own box arithmetic on the joints it found (run_estimator_ps.py:96-107).  The
+    pass is a probe: the estimator's filters are reset afterwards, so the first tracked frame is still an unfiltered one
+    as in the reference.  Returns (x, y, w, h).
+    """
+    H_img, W_img = frame.shape[:2]
+    joints_2d, _ = estimator(frame, timestamp=timestamp)
+    estimator.reset()
+    x, y, w, h = bbox_update(joints_2d, W_img, H_img)
+    if w < 1 or h < 1:
+        return [0, 0, W_img, H_img]
     return [x, y, w, h]
 
 
