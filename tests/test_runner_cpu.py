@@ -79,3 +79,26 @@ def test_init_box_probes_the_whole_frame_then_resets():
     est2 = FakeEstimator(np.full((21, 2), 7.0))
     x, y, w, h = runner.bbox_update(est2.j2, 320, 240)
     assert runner.init_box(est2, frame) == ([x, y, w, h] if w >= 1 and h >= 1 else [0, 0, 320, 240])
+
+
+def test_render_2d_and_3d_to_files(tmp_path):
+    """SURVEY 8f rank 4 (rendering): limbs and rectangle land where the joints are; files are written and re-readable."""
+    from vnect_amd import render
+    from vnect_amd.estimator import VNectEstimator
+    img = np.full((240, 320, 3), 255, np.uint8)
+    j2 = np.zeros((21, 2))
+    j2[:, 0] = np.linspace(40, 200, 21)     # rows
+    j2[:, 1] = np.linspace(100, 180, 21)    # cols
+    out = render.draw_limbs_2d(img, j2, VNectEstimator.joint_parents, [90, 30, 100, 180])
+    assert out.shape == img.shape and out.dtype == np.uint8 and np.all(img == 255)   # the input is not drawn on
+    r, c = int(round((j2[2, 0] + j2[1, 0]) / 2)), int(round((j2[2, 1] + j2[1, 1]) / 2))
+    assert tuple(out[r, c]) == render.LIMB_BGR                     # middle of limb 2 -> 1 (BGR)
+    assert tuple(out[30, 140]) == render.RECT_BGR and tuple(out[5, 5]) == (255, 255, 255)
+    j3 = np.zeros((21, 3), np.float32)
+    j3[:, 0] = np.linspace(-300, 300, 21)
+    j3[:, 1] = np.linspace(-400, 400, 21)
+    v = render.draw_limbs_3d(j3, VNectEstimator.joint_parents)
+    assert v.shape == (400, 400, 3) and (v != 255).any()
+    p = tmp_path / "pose.png"
+    render.save(str(p), out)
+    assert np.array_equal(runner.load_bgr(str(p)), out)            # PNG round trip
