@@ -43,6 +43,27 @@ typedef __attribute__((address_space(1))) __bf16 gbf16;
 typedef __attribute__((address_space(1))) const float cgfloat;
 typedef __attribute__((address_space(1))) const __bf16 cgbf16;
 
+// Epilogue stores are write-through (`sc1`): the bytes leave the XCD's L2 while the kernel still runs instead of in the
+// write-back sweep at the kernel boundary, which every dependent launch behind this one waits for (A/B in one gpurun call:
+// 1010 -> 1023 frames/s fp32).  Same bytes, same order of arithmetic: results are unchanged.
+__device__ __forceinline__ void put_f32(gfloat* p, float v)
+{
+#if VNECT_AB == 2
+    *p = v;
+#else
+    __hip_atomic_store((float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void put_bf16(gbf16* p, float v)
+{
+    const __bf16 b = (__bf16)v;  // round to nearest even
+#if VNECT_AB
+    *p = b;
+#else
+    __hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // Buffer-addressed LDS-DMA (`buffer_load_dwordx4 v_off, s[srd], s_off offen lds`): address = base + v_off + s_off, 16 bytes per
 // lane to M0-base + lane * 16; a lane whose v_off is >= num_records fetches nothing and lands zeros.  The descriptor
 // type only exists in the device pass.
@@ -502,8 +523,8 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                     if (c.scale) o = o * sc + sh;
                     o = o + rs[r];
                     if constexpr (decltype(RELU)::value) o = __builtin_fmaxf(o, 0.f);
-                    if constexpr (decltype(OUTF32)::value) op[off0] = o;
-                    else op[off0] = (__bf16)o;  // round to nearest even
+                    if constexpr (decltype(OUTF32)::value) put_f32((gfloat*)op + off0, o);
+                    else put_bf16((gbf16*)op + off0, o);
                     op += ((r & 3) == 3 ? 5 : 1) * ldo;
                 }
             };
@@ -530,8 +551,8 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 if (relu) o = __builtin_fmaxf(o, 0.f);
                 if (m < h.M && n < nlim) {
                     const unsigned off = (unsigned)(op * ldo + (n - ncol0));  // tensors are far below 2^32 elements
-                    if (of32) outp[off] = o;
-                    else ((gbf16*)outp)[off] = (__bf16)o;
+                    if (of32) put_f32(outp + off, o);
+                    else put_bf16((gbf16*)outp + off, o);
                 }
             }
         }
