@@ -746,7 +746,7 @@ __global__ void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, in
             for (int e = 0; e < 4; e++) m[e] = v[e] > m[e] ? v[e] : m[e];
         }
     }
-    *(tx4*)(out + p * C + c) = __builtin_convertvector(m, tx4);  // exact: the maximum is one of the inputs
+    store_wt((tx4*)(out + p * C + c), __builtin_convertvector(m, tx4));  // exact: the maximum is one of the inputs
 }
 hipError_t launch_maxpool(const void* in, void* out, int S, int H, int W, int C, int Ho, int Wo, int bf16, hipStream_t st)
 {

@@ -71,6 +71,21 @@ struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])
     int bf16, out_f32;
 };
 
+// Write-through (`sc1`) vector stores for the small kernels between the conv launches: like the conv epilogue's, their output
+// leaves the L2 while the kernel runs instead of in the write-back at the kernel boundary the next launch waits behind.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename V>
+__device__ __forceinline__ void store_wt(V* p, V v)
+{
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8, "one dwordx4 / dwordx2 store");
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+#else
+template <typename V>
+__device__ __forceinline__ void store_wt(V* p, V v) { *p = v; }
+#endif
+
 hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st);  // KG: in-workgroup K groups (1, 2, 4)
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
 hipError_t conv_setup();  // one-time function attributes (dynamic LDS size)

@@ -85,7 +85,7 @@ __global__ void pyramid_kernel(const FrameParams* __restrict__ fp, const FrameDy
         }
     }
     f32x4 o = {tabs->lut[v[0]], tabs->lut[v[1]], tabs->lut[v[2]], 0.f};
-    *(tx4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4) = __builtin_convertvector(o, tx4);
+    store_wt((tx4*)(batch4 + (((long long)blockIdx.z * BOX + y) * BOX + x) * 4), __builtin_convertvector(o, tx4));
 }
 
 hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st)
