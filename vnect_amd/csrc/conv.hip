@@ -46,12 +46,13 @@ typedef __attribute__((address_space(1))) const __bf16 cgbf16;
 // Epilogue stores are write-through (`sc1`): the bytes leave the XCD's L2 while the kernel still runs instead of in the
 // write-back sweep at the kernel boundary, which every dependent launch behind this one waits for (A/B in one gpurun call:
 // 1010 -> 1023 frames/s fp32).  Same bytes, same order of arithmetic: results are unchanged.
+// (-DVNECT_AB=1, tools/ab.sh: plain stores again, to repeat the comparison.)
 __device__ __forceinline__ void put_f32(gfloat* p, float v)
 {
-#if VNECT_AB == 2
+#if VNECT_AB
     *p = v;
 #else
-    __hip_atomic_store((float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
 #endif
 }
 __device__ __forceinline__ void put_bf16(gbf16* p, float v)
