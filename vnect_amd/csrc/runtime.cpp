@@ -426,6 +426,16 @@ void choose_tile(Layer& L, long long npix)
             ((fBM == 64 && fBN == 64 && fKG == 1) || (fBM == 64 && fBN == 32 && fKG == 2) || (fBM == 32 && fBN == 32 && fKG == 4)))
             BM = fBM, BN = fBN, KG = fKG, ks = std::min(fks, nch / fKG);
     }
+    // tuning: VNECT_PLAN="layer=BM,BN,KG,ks;layer=..." overrides single layers (tools/layer_table.py shows the effect)
+    if (const char* plan = getenv("VNECT_PLAN")) {
+        const std::string key = L.name + "=";
+        const char* p = strstr(plan, key.c_str());
+        int fBM = 0, fBN = 0, fKG = 0, fks = 0;
+        if (p && (p == plan || p[-1] == ';') && sscanf(p + key.size(), "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) == 4 && fks >= 1 && fks <= 8 &&
+            L.a.cpt % std::max(fKG, 1) == 0 &&
+            ((fBM == 64 && fBN == 64 && fKG == 1) || (fBM == 64 && fBN == 32 && fKG == 2) || (fBM == 32 && fBN == 32 && fKG == 4)))
+            BM = fBM, BN = fBN, KG = fKG, ks = std::min(fks, nch / fKG);
+    }
     L.BM = BM, L.BN = BN, L.KG = KG, L.a.ksplit = ks;
 }
 
