@@ -64,3 +64,30 @@ def test_frame_validation():
         _native._as_frame(np.zeros((4, 4, 3), np.float32))
     crop = np.zeros((100, 100, 3), np.uint8)[10:50, 20:60]  # non-contiguous rows are passed through by stride
     assert _native._as_frame(crop).strides[0] == 300
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under vnect_amd/ (Python, C++, HIP) may import, open or link it, and the product
+    library's dynamic dependencies must not name it.  (bench.py's cpu_baseline leg and __graft_entry__.smoke() are the only
+    callers outside tests/.)"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "vnect_amd")
+    offenders = []
+    for d, _, files in os.walk(pkg):
+        if os.path.basename(d) in ("lib", "__pycache__") or os.sep + "lib" + os.sep in d + os.sep:
+            continue
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                continue
+            text = open(os.path.join(d, f), errors="replace").read()
+            if re.search(r"^\s*(import|from)\s+oracle\b|libvnect_oracle|vnect_oracle\.h|oracle/_build|\bvo_[a-z_]+\(", text, re.M):
+                offenders.append(os.path.relpath(os.path.join(d, f), root))
+    assert not offenders, offenders
+    so = os.path.join(pkg, "lib", "libvnect_hip.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "NEEDED" in needed and "oracle" not in needed
+    # there is no CPU fallback either: the loader raises if the library is missing instead of substituting anything
+    src = open(os.path.join(pkg, "_native.py")).read()
+    assert "raise" in src and "oracle" not in src
