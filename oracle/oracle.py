@@ -64,6 +64,12 @@ def lib():
                                          c_f64p, c_f32p]
         L.vo_est_infer.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, c_f64p,
                                    c_f32p]
+        # The blocked SGEMM stops scaling at ~16 threads (bench.py measured 8 / 16 / 32 / 64 / 128 -> 3.6 / 4.0 / 3.7 / 2.9 / 1.6
+        # frames/s on the GPU box) and a 256-thread team on a box whose CPU share is 16 cores has taken 44 s per frame:
+        # cap the team unless VNECT_ORACLE_THREADS says otherwise.  Results do not depend on the thread count.
+        L.vo_set_threads.argtypes = [C.c_int]
+        want = os.environ.get("VNECT_ORACLE_THREADS")
+        L.vo_set_threads(int(want) if want else min(16, len(os.sched_getaffinity(0))))
         _lib = L
     return _lib
 

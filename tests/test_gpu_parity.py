@@ -164,6 +164,32 @@ def test_preprocess_bit_exact(weights, shape, smooth, scales):
     assert np.array_equal(batch, rb)
 
 
+def test_preprocess_fuzz_shapes(h3):
+    """a10 over 32 seeded frame shapes (long side 40 .. 1500, aspect ratios up to 6:1, odd sizes): every one bit-exact against the
+    oracle, or rejected by both (utils.py:98-103 cannot place a crop whose scaled long side is not 368)."""
+    import oracle
+    from tests import helpers
+    from vnect_amd._native import VnectError
+    rng = np.random.RandomState(20240807)
+    checked = 0
+    for k in range(32):
+        long_side = int(rng.randint(40, 1501))
+        short = max(8, int(long_side / rng.uniform(1.0, 6.0)))
+        H, W = (long_side, short) if k & 1 else (short, long_side)
+        frame = helpers.synth_frame(500 + k, H, W, smooth=bool(k & 2))
+        try:
+            rb, rs, roff = oracle.gen_input_batch(frame, BASELINE_SCALES)
+        except Exception:
+            with pytest.raises(VnectError):
+                h3.preprocess(frame)
+            continue
+        b, s, off = h3.preprocess(frame)
+        assert s == rs and off == roff, (H, W)
+        assert np.array_equal(b, rb), (H, W)
+        checked += 1
+    assert checked >= 24
+
+
 def test_preprocess_strided_crop(h3):
     """Callers pass crops of a larger frame (run_estimator_ps.py:87): row stride != 3*W."""
     import oracle
@@ -314,6 +340,25 @@ def test_end_to_end_vs_oracle(h3, ref3, oracle_net):
         assert np.all(d3 <= tol), k
         assert same.mean() >= 0.8, "too many arg-max flips: %d/21" % (21 - same.sum())
     print("worst 3-D excess over tolerance:", worst3)
+
+
+def test_end_to_end_nonsquare_frames(h3, ref3):
+    """Whole __call__ on frames that are not 368x368 (the size of pic/test_pic.jpg, a landscape VGA-like crop, a small portrait
+    one): squarify scaler and centring offsets enter the un-mapping (estimator.py:137-139).  Same gates as the square case."""
+    from tests import helpers
+    h3.reset_filters()
+    ref3.reset()
+    for k, (H, W) in enumerate([(538, 368), (240, 320), (200, 120), (538, 368)]):
+        frame = helpers.synth_frame(4321 + k, H, W, smooth=True)
+        t = T0 + 100 + k / 30
+        j2, j3 = h3.infer(frame, t, t + 0.001)
+        r2, r3 = ref3(frame, t, t + 0.001)
+        scaler = 368.0 / max(H, W)
+        same = np.all(np.abs(j2 - r2) <= 1e-6 / scaler + 1e-9, axis=1)
+        assert same.mean() >= 0.8, "too many arg-max flips at %dx%d: %d/21" % (H, W, 21 - same.sum())
+        assert np.all(j2[same] == r2[same])  # identical f64 arithmetic wherever the arg-max agrees
+        d3 = np.abs(j3 - r3)[same]
+        assert np.all(d3 <= 0.05 + 1e-4 * np.abs(r3)[same]), (H, W)
 
 
 @pytest.mark.parametrize("lanes,graph", [(1, True), (2, True), (2, False), (3, True)])
