@@ -226,6 +226,11 @@ def main():
         if os.path.exists(rj):
             rocprof_us = json.load(open(rj)).get("conv_avg_us_per_launch")
         peak = PEAK_FP32_MFMA if args.precision == "fp32" else PEAK_BF16_MFMA
+        # what the vendor libraries need for the same layers (committed measurement of tools/vendor_ref.py, same box class)
+        vendor = None
+        vj = os.path.join(ROOT, "profiles", "r01_vendor_ref.json")
+        if os.path.exists(vj):
+            vendor = json.load(open(vj)).get(args.precision)
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": "frames/sec, 368x368 3-scale VNect inference",
@@ -267,7 +272,8 @@ def main():
                          kernel_ms_per_frame=round(conv_ms, 4), flops_per_frame=FLOPS_PER_FRAME,
                          conv_stack_span_ms=round(tim["net_ms"] / nprof, 4),
                          hip_event_frame_ms=round(tim["total_ms"] / nprof, 4),
-                         traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, profiles/ (per frame)"),
+                         traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, profiles/ (per frame)",
+                         vendor_libraries_same_layers=vendor),
         }
     h.close()
     if rank == 0:
