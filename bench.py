@@ -51,6 +51,37 @@ def cpu_baseline(weights, budget_s):
                       "of %d host cores: more are slower)" % (n, dt, len(os.sched_getaffinity(0)))}
 
 
+def cpu_framework_baseline(weights, budget_s):
+    """A framework-grade stand-in for the reference's TF-CPU path (TF1 cannot run here): the same frames through
+    torch-CPU (oneDNN) for the network, fp32, with the oracle's pre- and post-processing around it.  Reported beside
+    `cpu_baseline`, labelled as a proxy; never a target."""
+    import torch
+    import oracle
+    from tests import helpers, torch_net
+    threads = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(threads)
+    est = oracle.OracleEstimator(weights=weights, scales=SCALES)
+    frames = [helpers.synth_frame(1234 + k) for k in range(4)]
+
+    def frame(k, t):
+        batch, scaler, off = oracle.gen_input_batch(frames[k % 4], SCALES)
+        with torch.inference_mode():
+            maps = torch_net.forward(weights, batch, dtype=torch.float32).numpy()
+        return est.postprocess(maps, t, t, scaler, off[0], off[1])
+
+    frame(0, 1.0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        frame(n, 2.0 + n / 30)
+        n += 1
+        dt = time.perf_counter() - t0
+        if (dt >= budget_s and n >= 3) or n >= 400:
+            break
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "proxy: torch-CPU (oneDNN) fp32 network + oracle pre/post",
+            "sample": "%d frames of the same workload in %.1f s on %d threads of %d host cores (torch %s)"
+                      % (n, dt, threads, len(os.sched_getaffinity(0)), torch.__version__)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +310,10 @@ def main():
     if rank == 0:
         if args.cpu_seconds > 0 and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(weights, args.cpu_seconds)
+            try:
+                out["cpu_baseline_framework"] = cpu_framework_baseline(weights, min(args.cpu_seconds, 8.0))
+            except Exception as e:  # noqa: the proxy is optional evidence, the bench line is not
+                out["cpu_baseline_framework"] = {"error": str(e)[:200]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
