@@ -74,7 +74,16 @@ if ft and wt and res.get("frames_profiled"):
         "hbm_bytes_per_frame": (conv_f * 2 + conv_w) * 1024, "per_kernel": per_kernel}
     json.dump(traffic, open(os.path.join(sumdir, rnd + "_traffic.json"), "w"), indent=1)
     res["conv_hbm_bytes_per_frame"] = traffic["hbm_bytes_per_frame"]
-for tag in ("stats", "fetch", "write"):
+mt, mn = counter_sum("mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+if mt and res.get("frames_profiled") and res.get("conv_ms_per_frame"):
+    fr = res["frames_profiled"]
+    busy = sum(v for k, v in mt.items() if "conv_stream" in k) / fr  # SIMD-cycles per frame, all 1024 SIMDs
+    res["mfma_busy_simd_cycles_per_frame"] = busy
+    # utilisation over the time the conv kernels occupy the stream (conv_ms_per_frame, from the --stats pass), against the
+    # 2.4 GHz of the peak figure: busy / (1024 SIMDs x 2.4e9 x seconds)
+    res["mfma_util_vs_2p4GHz"] = busy / (1024 * 2.4e9 * res["conv_ms_per_frame"] * 1e-3)
+    res["mfma_note"] = "SQ_VALU_MFMA_BUSY_CYCLES summed over the conv_stream_kernel launches of a frame (64 cycles per v_mfma_f32_32x32x2_f32, padded tiles included)"
+for tag in ("stats", "fetch", "write", "mfma"):
     b = os.path.join(out, "bench_%s.json" % tag)
     if os.path.exists(b) and os.path.getsize(b):
         try:
