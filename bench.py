@@ -247,7 +247,7 @@ def main():
         exec_ms = tim["conv_ms"] / nprof
         achieved = FLOPS_PER_FRAME / (len(SCALES) if args.pyramid else 1) / (conv_ms * 1e-3) / 1e12  # per GPU
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        tj = os.path.join(ROOT, "profiles", "traffic_latest.json" if args.precision == "fp32" else "r01_traffic_bf16.json")
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get("hbm_bytes_per_frame")
         # rocprofv3's average for the same kernels (committed summary of the same command): its durations run from the
@@ -287,7 +287,7 @@ def main():
                          **({"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                              "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic} if args.precision == "fp32" else
                             {"bound": "hbm", "achieved": round(BF16_BYTES_PER_FRAME / (conv_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                             "unit": "GB/s", "frac": round(BF16_BYTES_PER_FRAME / (conv_ms * 1e-3) / 8e12, 4), "traffic": None,
+                             "unit": "GB/s", "frac": round(BF16_BYTES_PER_FRAME / (conv_ms * 1e-3) / 8e12, 4), "traffic": traffic,
                              "algorithmic_bytes_per_frame": BF16_BYTES_PER_FRAME,
                              "mfma_view": {"achieved_tflops": round(achieved, 2), "peak": PEAK_BF16_MFMA,
                                            "frac": round(achieved / PEAK_BF16_MFMA, 4)}}),

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
 # --no-aux: the auxiliary legs of bench.py overlap frames on purpose; the statistics here describe the synchronous headline loop
-STEPS="--steps 100 --warmup 10 --cpu-seconds 0 --no-aux"
+STEPS="--steps 100 --warmup 10 --cpu-seconds 0 --no-aux ${@:2}"   # e.g. tools/profile_round.sh r01_bf16 --precision bf16
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $R -- python3 bench.py $STEPS > $OUT/bench_stats.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $R -- python3 bench.py $STEPS > $OUT/bench_fetch.json 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $R -- python3 bench.py $STEPS > $OUT/bench_write.json 2> $OUT/write.log
