@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VNECT_ABI_VERSION 1
+#define VNECT_ABI_VERSION 2
 #define VNECT_MAX_SCALES 8
 #define VNECT_BOX 368      /* src/estimator.py:19 box_size   */
 #define VNECT_HM 46        /* box_size / hm_factor (:21)     */
@@ -34,7 +34,11 @@ enum {
     VNECT_E_NODEVICE = -4,  /* no usable gfx950 device                              */
     VNECT_E_TIMESTAMP = -5, /* timestamp equals the previous one: the reference raises
                                ZeroDivisionError at src/OneEuroFilter.py:66          */
-    VNECT_E_COMM = -6       /* RCCL error                                           */
+    VNECT_E_COMM = -6,      /* RCCL / peer-access error                             */
+    VNECT_E_TIMEORDER = -7, /* timestamp earlier than the previous one: the reference's negative freq drives
+                               alpha out of (0, 1] and LowPassFilter.__setAlpha raises ValueError
+                               (src/OneEuroFilter.py:19-23, 58-66)                   */
+    VNECT_E_INTERNAL = -8   /* host allocation failure or an internal C++ exception, caught at the boundary */
 };
 
 enum { VNECT_FP32 = 0, VNECT_BF16 = 1 };
@@ -66,7 +70,15 @@ typedef struct vnect_config {
                                          and overlaps with them; only the joints kernels stay in order (the OneEuro filters
                                          are a chain).  Results are bit-identical to sequential execution; each extra lane
                                          costs one more activation arena (~0.1 GB)                                          */
+    int32_t preprocess_only;          /* 1: the handle serves vnect_preprocess (and vnect_set_scales) only -- the static
+                                         gen_input_batch of src/estimator.py:70-81 needs no session either: no weights, no
+                                         launch plan, ~20 MB of device memory; vnect_finalize and inference are refused      */
+    int32_t exchange;                 /* pyramid sharding: how a rank's maps reach the others (VNECT_XCHG_*)                 */
 } vnect_config;
+
+enum { VNECT_XCHG_RCCL = 0,   /* ncclAllGather on the handle's stream (default)                                             */
+       VNECT_XCHG_P2P = 1 };  /* peer writes over xGMI: a copy kernel stores the rank's 710 976 B straight into every peer's
+                                 gather slot (hipDeviceEnablePeerAccess + IPC-mapped buffers), one flag per rank          */
 
 /* Replaces VNectEstimator.__init__ (src/estimator.py:27-68): session + graph + 42 + 63 filters. */
 int vnect_create(const vnect_config* cfg, vnect_handle** out);
@@ -111,10 +123,17 @@ int vnect_infer(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_s
  * upload copies a frame into slot; infer_resident runs __call__ on it without a host->device copy. */
 int vnect_upload_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride);
 int vnect_infer_resident(vnect_handle* h, int slot, double t2d, double t3d, double* joints_2d, float* joints_3d);
-/* Two-deep pipelining of the same call: submit enqueues a frame, collect waits for the oldest
- * un-collected one (FIFO).  At most 2 frames may be in flight. */
+/* Pipelining of the same call: submit enqueues a frame, collect waits for the oldest un-collected one (FIFO).
+ * At most max(lanes, 2) frames may be in flight (one lane: the second frame queues behind the first on its stream). */
 int vnect_submit_resident(vnect_handle* h, int slot, double t2d, double t3d);
 int vnect_collect(vnect_handle* h, double* joints_2d, float* joints_3d);
+
+/* Replaces VNectEstimator.joint_filter(joints, dim) (src/estimator.py:83-95) on its own: the handle's 2-D (dim 2: 21x2)
+ * or 3-D (dim 3: 21x3) OneEuro bank applied to caller-supplied joints at timestamp t (the reference reads time.time() once
+ * per call, :84).  Values travel as float64; values_are_f32 = 1 says they are numpy float32 scalars -- what the reference
+ * feeds the 3-D bank (:91-93) -- so numpy's scalar promotion rules (vnect_config::numpy_promotion) decide the arithmetic.
+ * Same timestamp errors as vnect_infer.  The filter state lives on the device; this runs one tiny kernel. */
+int vnect_joint_filter(vnect_handle* h, int dim, const double* joints_in, int values_are_f32, double t, double* joints_out);
 
 /* New filters, as constructing a fresh VNectEstimator would (src/estimator.py:46-52). */
 int vnect_reset_filters(vnect_handle* h);
@@ -170,6 +189,15 @@ int vnect_get_layer_stamps(vnect_handle* h, int idx, uint64_t* out24);
  * handle takes ONE image (its scale). */
 int vnect_comm_unique_id(void* id128);
 int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128);
+/* The same exchange by plain peer writes over xGMI instead of RCCL (vnect_config::exchange = VNECT_XCHG_P2P; SURVEY 8e asks for
+ * both, measured side by side: 711 KB per rank is ~4.6 us of wire time, a collective's launch + sync latency is tens of us).
+ * Every rank exports a 128-byte blob describing its exchange block (IPC memory handle + the address inside the exporting
+ * process), the host distributes the blobs (torch.distributed all_gather_object / files), and vnect_comm_p2p_init(rank, nranks,
+ * blobs[nranks * 128]) maps the peers' blocks (hipIpcOpenMemHandle across processes; hipDeviceEnablePeerAccess when the peer
+ * handle lives in this process).  Per frame one kernel stores the rank's maps into every peer's block, publishes a per-rank flag
+ * and gathers the peers' slots; a peer that does not show up within ~2 s makes the frame fail with VNECT_E_COMM, never hang. */
+int vnect_comm_p2p_export(vnect_handle* h, void* blob128);
+int vnect_comm_p2p_init(vnect_handle* h, int rank, int nranks, const void* blobs);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libvnect_oracle.so")
+# VNECT_ORACLE_SO: another build of the same sources (the ASan + UBSan one, `make -C oracle asan`)
+_SO = os.environ.get("VNECT_ORACLE_SO") or os.path.join(_HERE, "_build", "libvnect_oracle.so")
 _lib = None
 
 c_f32p = C.POINTER(C.c_float)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"vnect_handle", "vnect_config", "vnect_timings", "vnect_layer_info"}
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     L = _native.lib()  # getattr on every symbol happens inside
-    assert L.vnect_abi_version() == 1
+    assert L.vnect_abi_version() == _native.ABI_VERSION
 
 
 def test_header_cites_reference_lines():
@@ -36,8 +36,9 @@ def test_header_cites_reference_lines():
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
-    assert C.sizeof(_native.Config) == 120
+    assert C.sizeof(_native.Config) == 128
     assert _native.Config.keep_activations.offset == 112 and _native.Config.lanes.offset == 116
+    assert _native.Config.preprocess_only.offset == 120 and _native.Config.exchange.offset == 124
     assert _native.Config.scales.offset == 16
     assert C.sizeof(_native.LayerInfo) == 64 + 7 * 4 + 4 + 16
 
@@ -64,6 +65,44 @@ def test_frame_validation():
         _native._as_frame(np.zeros((4, 4, 3), np.float32))
     crop = np.zeros((100, 100, 3), np.uint8)[10:50, 20:60]  # non-contiguous rows are passed through by stride
     assert _native._as_frame(crop).strides[0] == 300
+    # views the reference accepts but a (pointer, positive row stride) pair cannot describe are copied, not rejected
+    img = np.arange(6 * 5 * 3, dtype=np.uint8).reshape(6, 5, 3)
+    for view in (img[::-1], img[:, ::-1], img[..., ::-1], np.broadcast_to(img[:1], (6, 5, 3))):
+        f = _native._as_frame(view)
+        assert f.strides == (15, 3, 1) and np.array_equal(f, view)
+
+
+def test_error_paths_return_codes_without_a_gpu():
+    """Null handles / arguments come back as codes from every entry point (no abort, no exception), and the message of a failed
+    vnect_create is per thread."""
+    import ctypes as C
+    import threading
+    L = _native.lib()
+    assert L.vnect_finalize(None) == _native.E_ARG
+    assert L.vnect_set_weight(None, b"x", None, None, 1) == _native.E_ARG
+    assert L.vnect_joint_filter(None, 2, None, 0, 1.0, None) == _native.E_ARG
+    assert L.vnect_collect(None, None, None) == _native.E_ARG
+    assert L.vnect_comm_unique_id(None) == _native.E_ARG
+    L.vnect_destroy(None)
+    seen = {}
+
+    def worker():
+        seen["before"] = L.vnect_last_error(None)
+        cfg = _native.Config()
+        cfg.struct_size = C.sizeof(_native.Config)
+        cfg.num_scales = 99
+        h = C.c_void_p()
+        seen["rc"] = L.vnect_create(C.byref(cfg), C.byref(h))
+        seen["after"] = L.vnect_last_error(None)
+
+    cfg = _native.Config()
+    cfg.struct_size = 7
+    h = C.c_void_p()
+    assert L.vnect_create(C.byref(cfg), C.byref(h)) == _native.E_ARG and h.value is None
+    t = threading.Thread(target=worker)
+    t.start(), t.join()
+    assert seen["rc"] == _native.E_ARG and b"num_scales" in seen["after"] and seen["before"] == b""
+    assert b"struct_size" in L.vnect_last_error(None)   # this thread's message is untouched by the other thread's failure
 
 
 def test_product_never_touches_the_oracle():

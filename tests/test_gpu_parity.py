@@ -313,52 +313,84 @@ def test_argmax_ties_and_planted_peaks(weights):
 
 
 # ------------------------------------------------------------------------------------------ end to end
-def test_end_to_end_vs_oracle(h3, ref3, oracle_net):
-    """Whole __call__ over 4 frames.  Heatmaps of random weights are noise-like, so joints_2d is gated by the
-    tie rule: equal, or the oracle's heatmap value at the GPU arg-max is within eps of its maximum."""
-    import oracle
+class _EndToEnd:
+    """The end-to-end gate, applied to EVERY frame and EVERY joint (no allowance for a fraction of mismatching joints).
+
+    A frame's result is split into the two things that can differ from the CPU oracle:
+      (1) the conv stack's final maps: |GPU - oracle| <= 1e-4 * max|oracle| (fp32 summation order);
+      (2) everything after them -- merge, arg-max, both filter banks, read-off, un-mapping -- which is exact arithmetic:
+          the GPU's joints must equal, BIT FOR BIT, the oracle's post-processing of the GPU's own maps (a second oracle
+          estimator whose filters advance in lockstep).
+    Where (1) moves a heat-map maximum, np.argmax may legally pick another cell: the tie rule (utils.py:153-175 takes the first
+    maximum) accepts a different raw arg-max only if the ORACLE's upsampled heat-map at the GPU's arg-max is within the
+    map tolerance of its maximum.  A joint whose raw arg-max has agreed on every frame so far has comparable filter
+    state, and is additionally held to joints_2d equal (1e-6) and joints_3d within 0.05 mm + 1e-4 * |v| of the full
+    oracle chain."""
+
+    def __init__(self, scales, oracle_net, nep50=False):
+        import oracle
+        self.scales, self.net = scales, oracle_net
+        self.full = oracle.OracleEstimator(scales=scales, net=oracle_net, nep50=nep50)   # oracle maps -> oracle joints
+        self.post = oracle.OracleEstimator(scales=scales, nep50=nep50)                   # GPU maps -> oracle joints
+        self.clean = np.ones(21, bool)  # raw arg-max equal on every frame so far
+        self.ties = 0
+        self.worst3 = 0.0
+
+    def check(self, frame, t2d, t3d, j2, j3, gpu_maps, tag=""):
+        import oracle
+        frame = np.ascontiguousarray(frame)
+        batch, scaler, (ox, oy) = oracle.gen_input_batch(frame, self.scales)
+        ref_maps = self.net.forward(batch)
+        top = float(np.abs(ref_maps).max())
+        assert float(np.abs(gpu_maps - ref_maps).max()) <= 1e-4 * top, tag                      # (1)
+        p2, p3 = self.post.postprocess(gpu_maps, t2d, t3d, scaler, ox, oy)
+        assert np.array_equal(j2, p2) and np.array_equal(j3, p3), tag                          # (2) bit for bit
+        r2, r3 = self.full.postprocess(ref_maps, t2d, t3d, scaler, ox, oy)  # == the oracle's whole __call__ on this frame
+        avg_ref = oracle.merge_scales(ref_maps, self.scales)[0]
+        raw_ref = oracle.extract_2d(avg_ref)
+        raw_gpu = oracle.extract_2d(oracle.merge_scales(gpu_maps, self.scales)[0])
+        for j in range(21):                                                                    # tie rule, every joint
+            if np.array_equal(raw_gpu[j], raw_ref[j]):
+                continue
+            up = oracle.resize(np.ascontiguousarray(avg_ref[:, :, j]), 8.0)
+            assert up[int(raw_gpu[j, 0]), int(raw_gpu[j, 1])] >= up.max() - 1e-4 * top, (tag, j)
+            self.clean[j] = False
+            self.ties += 1
+        c = self.clean
+        assert np.all(np.abs(j2[c] - r2[c]) <= 1e-6 / min(scaler, 1.0) + 1e-9), tag
+        d3 = np.abs(j3 - r3)
+        # the root joint (14) is subtracted from every row: rows are comparable only while joint 14 is clean too
+        if c[14]:
+            tol = 0.05 + 1e-4 * np.abs(r3)
+            assert np.all(d3[c] <= tol[c]), tag
+            if c.any():
+                self.worst3 = max(self.worst3, float((d3[c] - tol[c]).max()))
+
+
+def test_end_to_end_vs_oracle(h3, oracle_net):
+    """Whole __call__ over 4 frames against the oracle: see _EndToEnd (every frame, every joint)."""
     from tests import helpers
     h3.reset_filters()
-    ref3.reset()
-    worst3 = 0.0
+    e2e = _EndToEnd(BASELINE_SCALES, oracle_net)
     for k in range(4):
         frame = helpers.synth_frame(1234 + k, smooth=True)
         t = T0 + k / 30
         j2, j3 = h3.infer(frame, t, t + 0.001)
-        r2, r3 = ref3(frame, t, t + 0.001)
-        if k == 0:  # first frame: filters are the identity, joints_2d are raw arg-max positions
-            batch, _, _ = oracle.gen_input_batch(frame, BASELINE_SCALES)
-            avg = oracle.merge_scales(oracle_net.forward(batch), BASELINE_SCALES)[0]
-            for j in range(21):
-                if not np.array_equal(j2[j], r2[j]):
-                    up = oracle.resize(np.ascontiguousarray(avg[:, :, j]), 8.0)
-                    assert up[int(j2[j, 0]), int(j2[j, 1])] >= up.max() - 1e-4 * np.abs(avg).max(), j
-        same = np.all(np.abs(j2 - r2) <= 1e-6, axis=1)
-        d3 = np.abs(j3 - r3)[same]
-        tol = 0.05 + 1e-4 * np.abs(r3)[same]
-        worst3 = max(worst3, float((d3 - tol).max()) if d3.size else 0.0)
-        assert np.all(d3 <= tol), k
-        assert same.mean() >= 0.8, "too many arg-max flips: %d/21" % (21 - same.sum())
-    print("worst 3-D excess over tolerance:", worst3)
+        e2e.check(frame, t, t + 0.001, j2, j3, h3.activation("res5c_branch2c"), k)
+    print("legal arg-max ties: %d, worst 3-D excess over tolerance: %.3g" % (e2e.ties, e2e.worst3))
 
 
-def test_end_to_end_nonsquare_frames(h3, ref3):
+def test_end_to_end_nonsquare_frames(h3, oracle_net):
     """Whole __call__ on frames that are not 368x368 (the size of pic/test_pic.jpg, a landscape VGA-like crop, a small portrait
-    one): squarify scaler and centring offsets enter the un-mapping (estimator.py:137-139).  Same gates as the square case."""
+    one): squarify scaler and centring offsets enter the un-mapping (estimator.py:137-139).  Same gate as the square case."""
     from tests import helpers
     h3.reset_filters()
-    ref3.reset()
+    e2e = _EndToEnd(BASELINE_SCALES, oracle_net)
     for k, (H, W) in enumerate([(538, 368), (240, 320), (200, 120), (538, 368)]):
         frame = helpers.synth_frame(4321 + k, H, W, smooth=True)
         t = T0 + 100 + k / 30
         j2, j3 = h3.infer(frame, t, t + 0.001)
-        r2, r3 = ref3(frame, t, t + 0.001)
-        scaler = 368.0 / max(H, W)
-        same = np.all(np.abs(j2 - r2) <= 1e-6 / scaler + 1e-9, axis=1)
-        assert same.mean() >= 0.8, "too many arg-max flips at %dx%d: %d/21" % (H, W, 21 - same.sum())
-        assert np.all(j2[same] == r2[same])  # identical f64 arithmetic wherever the arg-max agrees
-        d3 = np.abs(j3 - r3)[same]
-        assert np.all(d3 <= 0.05 + 1e-4 * np.abs(r3)[same]), (H, W)
+        e2e.check(frame, t, t + 0.001, j2, j3, h3.activation("res5c_branch2c"), (H, W))
 
 
 @pytest.mark.parametrize("lanes,graph", [(1, True), (2, True), (2, False), (3, True)])
@@ -476,12 +508,11 @@ def test_errors_mirror_reference(weights):
 
 def test_tracking_loop_variable_crops(weights, oracle_net):
     """run_estimator_ps.py:80-109 headless: the crop changes every frame, so squarify/resize tables are rebuilt per
-    call; every frame is checked against the oracle fed the same crop (2-D by the tie rule, 3-D by tolerance)."""
-    import oracle
+    call; every frame and every joint is checked against the oracle fed the same crop (_EndToEnd)."""
     from vnect_amd import VNectEstimator, runner
     scales = [1.0, 0.8, 0.6]
     est = VNectEstimator(scales=scales, weights=weights, verbose=False)
-    ref = oracle.OracleEstimator(scales=scales, net=oracle_net)
+    e2e = _EndToEnd(scales, oracle_net)
     frames = list(runner.synthetic_stream(3, 4, 480, 640))
     rect, sizes = [40, 30, 500, 400], set()
     for k, frame in enumerate(frames):
@@ -490,10 +521,7 @@ def test_tracking_loop_variable_crops(weights, oracle_net):
         sizes.add(crop.shape)
         t = T0 + k / 30
         j2, j3 = est(crop, timestamp=(t, t + 0.001))
-        r2, r3 = ref(np.ascontiguousarray(crop), t, t + 0.001)
-        same = np.all(np.abs(j2 - r2) <= 1e-6, axis=1)
-        assert same.mean() >= 0.8, (k, int(same.sum()))
-        assert np.all(np.abs(j3 - r3)[same] <= 0.05 + 1e-4 * np.abs(r3)[same]), k
+        e2e.check(crop, t, t + 0.001, j2, j3, est.handle.activation("res5c_branch2c"), k)
         j2[:, 0] += y
         j2[:, 1] += x
         rect = runner.bbox_update(j2, 640, 480)
@@ -534,10 +562,134 @@ def test_pyramid_shards_reassemble(weights, oracle_net):
     ref = oracle.OracleEstimator(scales=BASELINE_SCALES)
     o2, o3 = ref.postprocess(gathered, T0, T0 + 0.001, scaler, ox, oy)
     assert np.array_equal(j2, o2) and np.array_equal(j3, o3)    # a sharded rank's post-processing == oracle on the gathered maps
-    f2, f3 = full.postprocess(fmaps, T0, T0 + 0.001, scaler, ox, oy)
-    same = np.all(j2 == f2, axis=1)
-    assert same.mean() >= 0.8 and np.all(np.abs(j3 - f3)[same] <= 0.05 + 1e-4 * np.abs(f3)[same])
+    # sharded vs unsharded conv stack differ by fp32 rounding only (checked per rank above); their post-processing is
+    # exact arithmetic, so the unsharded handle fed the GATHERED maps must return the sharded result bit for bit
+    f2, f3 = full.postprocess(gathered, T0, T0 + 0.001, scaler, ox, oy)
+    assert np.array_equal(j2, f2) and np.array_equal(j3, f3)
     for h in ranks + [full]:
+        h.close()
+
+
+def test_pyramid_p2p_three_ranks_one_process(weights):
+    """configs[3] with the exchange by peer writes (vnect_config::exchange = VNECT_XCHG_P2P): three rank-handles of this
+    process store their maps into each other's exchange blocks, publish a flag per rank and gather.  Six frames (both
+    parities of the double-buffered blocks, reused three times): every rank returns the same joints, and they equal, bit for
+    bit, the unsharded handle's post-processing of the stacked per-rank maps."""
+    from tests import helpers
+    n = _native()
+    ranks = [n.Handle(BASELINE_SCALES, pyramid=(r, 3), exchange=n.XCHG_P2P) for r in range(3)]
+    for h in ranks:
+        h.set_weights(weights)
+        h.finalize()
+    with pytest.raises(n.VnectError):       # peers not connected yet: refuse, do not hang
+        ranks[0].infer(helpers.synth_frame(1), T0, T0)
+    blobs = [h.p2p_export() for h in ranks]
+    for r, h in enumerate(ranks):
+        h.p2p_init(r, 3, blobs)
+    full = _handle(BASELINE_SCALES, weights)
+    for k in range(6):
+        frame = helpers.synth_frame(7000 + k, 368 + 10 * (k % 2), 368 - 24 * (k % 3), smooth=True)
+        t = T0 + k / 30
+        for h in ranks:
+            h.upload_frame(k % 4, frame)
+        for h in ranks:                     # all three in flight: each waits in-kernel for the others' maps
+            h.submit_resident(k % 4, t, t + 0.001)
+        res = [h.collect() for h in ranks]
+        for r in (1, 2):
+            assert np.array_equal(res[r][0], res[0][0]) and np.array_equal(res[r][1], res[0][1]), (k, r)
+        gathered = np.concatenate([h.activation("res5c_branch2c") for h in ranks])
+        _, scaler, (ox, oy) = full.preprocess(frame, want_batch=False)
+        f2, f3 = full.postprocess(gathered, t, t + 0.001, scaler, ox, oy)
+        assert np.array_equal(res[0][0], f2) and np.array_equal(res[0][1], f3), k
+    for h in ranks + [full]:
+        h.close()
+
+
+def test_pyramid_p2p_missing_peer_fails_the_frame(weights, monkeypatch):
+    """A rank whose peers never show up must get VNECT_E_COMM from the frame after the bounded wait -- never a hang."""
+    from tests import helpers
+    n = _native()
+    monkeypatch.setenv("VNECT_XCHG_SPINS", "20000")
+    ranks = [n.Handle([1.0, 0.7], pyramid=(r, 2), exchange=n.XCHG_P2P) for r in range(2)]
+    for h in ranks:
+        h.set_weights(weights)
+        h.finalize()
+    blobs = [h.p2p_export() for h in ranks]
+    for r, h in enumerate(ranks):
+        h.p2p_init(r, 2, blobs)
+    with pytest.raises(n.VnectError) as e:
+        ranks[0].infer(helpers.synth_frame(3), T0, T0)     # rank 1 never submits this frame
+    assert e.value.code == n.E_COMM
+    for h in ranks:
+        h.close()
+
+
+P2P_WORKER = r"""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, %r)
+from vnect_amd import _native
+from vnect_amd.weights import synthetic_weights
+from tests import helpers
+rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+scales = [1.0, 0.8, 0.6]
+h = _native.Handle(scales, pyramid=(rank, world), exchange=_native.XCHG_P2P)
+h.set_weights(synthetic_weights())
+h.finalize()
+open(os.path.join(d, "blob%%d.tmp" %% rank), "wb").write(h.p2p_export())
+os.rename(os.path.join(d, "blob%%d.tmp" %% rank), os.path.join(d, "blob%%d" %% rank))
+t0 = time.time()
+while not all(os.path.exists(os.path.join(d, "blob%%d" %% r)) for r in range(world)):
+    assert time.time() - t0 < 120
+    time.sleep(0.05)
+h.p2p_init(rank, world, [open(os.path.join(d, "blob%%d" %% r), "rb").read() for r in range(world)])
+out = []
+for k in range(4):
+    frame = helpers.synth_frame(8000 + k, smooth=True)
+    j2, j3 = h.infer(frame, 1.7e9 + k / 30, 1.7e9 + k / 30 + 0.001)
+    out.append([j2.tolist(), j3.astype(np.float64).tolist()])
+print(json.dumps(out), flush=True)
+h.close()
+"""
+
+
+def test_pyramid_p2p_across_processes(weights, tmp_path):
+    """The same exchange with one PROCESS per rank (the deployment shape: one process per GPU), all three on this box's one GPU:
+    the exchange blocks are IPC-mapped (hipIpcGetMemHandle / hipIpcOpenMemHandle), each rank waits in-kernel for the other
+    processes' stores.  All ranks must print the same joints, equal to the one-process sharded result (conv stack of one image
+    per rank, so compared against sharded handles here, not against the 3-image batch whose K split may differ)."""
+    import subprocess
+    import sys
+    from tests import helpers
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "p2p_worker.py"
+    script.write_text(P2P_WORKER % root)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] == outs[2]
+    # reference: the one-process form of the same three ranks
+    n = _native()
+    ranks = [n.Handle(BASELINE_SCALES, pyramid=(r, 3), exchange=n.XCHG_P2P) for r in range(3)]
+    for h in ranks:
+        h.set_weights(weights)
+        h.finalize()
+    blobs = [h.p2p_export() for h in ranks]
+    for r, h in enumerate(ranks):
+        h.p2p_init(r, 3, blobs)
+    for k in range(4):
+        frame = helpers.synth_frame(8000 + k, smooth=True)
+        for h in ranks:
+            h.upload_frame(0, frame)
+            h.submit_resident(0, 1.7e9 + k / 30, 1.7e9 + k / 30 + 0.001)
+        res = [h.collect() for h in ranks]
+        assert np.array_equal(np.array(outs[0][k][0]), res[0][0]), k
+        assert np.array_equal(np.array(outs[0][k][1]).astype(np.float32), res[0][1]), k
+    for h in ranks:
         h.close()
 
 
@@ -598,6 +750,16 @@ def test_bf16_path_gated_against_fp32(weights, oracle_net, h3):
     j2f, j3f = h3.infer(frame, T0, T0 + 0.001)
     assert np.all(np.isfinite(j2b)) and np.all(np.isfinite(j3b))
     close = np.all(np.abs(j2b - j2f) <= 8.0 / min(s, 1.0) + 1e-9, axis=1)
-    print("bf16 vs fp32 joints within one cell: %d/21, max 3-D diff on those %.3g mm"
-          % (close.sum(), float(np.abs(j3b - j3f)[close].max()) if close.any() else -1))
+    same = np.all(j2b == j2f, axis=1)
+    mb, mf = hb.activation("res5c_branch2c"), h3.activation("res5c_branch2c")
+    # 3-D read-off where both paths sit on the same pixel: the location maps differ by <= 3e-2 * max|map| (gate above), the
+    # read-off is a convex blend of 4 cells x 100 (mm), and the root joint's row is subtracted: 2 * 3e-2 * max|xyz maps| * 100
+    bound3 = 2 * 3e-2 * float(np.abs(mf[..., 21:]).max()) * 100
+    d3 = np.abs(j3b - j3f)
+    print("bf16 vs fp32 joints: %d/21 within one cell, %d/21 on the same pixel; max 3-D diff on those %.3g mm (bound %.3g)"
+          % (close.sum(), same.sum(), float(d3[same].max()) if same.any() else -1, bound3))
+    assert close.sum() >= 19, "bf16 moved %d of 21 joints by more than one heat-map cell" % (21 - close.sum())
+    if same[14]:
+        assert np.all(d3[same] <= bound3)
+    assert float(np.abs(mb - mf).max()) <= 3e-2 * float(np.abs(mf).max())
     hb.close()

@@ -1,0 +1,251 @@
+"""GPU (MI355X): the rest of the reference's call surface and the rows SURVEY 8(f) marks "next", through the C ABI.
+
+joint_filter (estimator.py:83-95), weight files (caffe2pkl.py:83-88 / vnect_model.py:219-236), the person-box initialiser
+(hog_box.py:25-58), the static gen_input_batch (estimator.py:70-81), timestamp errors (OneEuroFilter.py:19-23,65-66) and the
+no-exception-crosses-the-boundary promise of include/vnect_abi.h.
+"""
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+T0 = 1.7e9
+BASELINE_SCALES = [1.0, 0.8, 0.6]
+
+
+def _est(weights, **kw):
+    from vnect_amd import VNectEstimator
+    return VNectEstimator(weights=weights, verbose=False, **kw)
+
+
+# ------------------------------------------------------------------------------------------ joint_filter (row b / a14)
+@pytest.mark.parametrize("promo", ["legacy", "nep50"])
+def test_joint_filter_in_place_bit_exact(weights, promo):
+    """VNectEstimator.joint_filter(joints, dim) alone: in place, returns its argument, float64 for the 2-D bank and numpy's
+    float32 scalar promotion for the 3-D bank -- bit-exact against the oracle's OneEuro filters (themselves bit-exact against
+    the imported reference class, tests/test_golden.py) over 40 calls with irregular time steps."""
+    import oracle
+    est = _est(weights, scales=[1.0], numpy_promotion=promo)
+    cfg2 = dict(freq=30, mincutoff=1.7, beta=0.3, dcutoff=0.4)   # estimator.py:34-45
+    cfg3 = dict(freq=30, mincutoff=0.8, beta=0.4, dcutoff=0.4)
+    ref2 = [[oracle.OneEuro(**cfg2) for _ in range(2)] for _ in range(21)]
+    post = oracle.OracleEstimator(scales=[1.0], nep50=(promo == "nep50"))
+    rng = np.random.RandomState(7)
+    t = T0
+    for k in range(40):
+        t += 1 / 30 + 0.002 * (k % 4)
+        a2 = 184 + 60 * np.sin(0.2 * k + np.arange(42).reshape(21, 2)) + rng.uniform(-3, 3, (21, 2))
+        want2 = np.array([[ref2[j][c](a2[j, c], t) for c in range(2)] for j in range(21)])
+        got = est.joint_filter(a2, dim=2, timestamp=t)
+        assert got is a2 and a2.dtype == np.float64                 # in place, as estimator.py:86-88 assigns
+        assert np.array_equal(a2, want2), k
+    # 3-D bank: float32 joints, in place; the first call of a OneEuro filter is the identity (OneEuroFilter.py:25-34,69-70).
+    # The float32-fed chain itself is checked frame by frame in test_joint_filter_3d_chain_vs_reference_recording.
+    j3 = rng.uniform(-500, 500, (21, 3)).astype(np.float32)
+    keep = j3.copy()
+    out = est.joint_filter(j3, dim=3, timestamp=T0)
+    assert out is j3 and j3.dtype == np.float32 and np.array_equal(j3, keep)
+    j3b = (keep + np.float32(1.5)).astype(np.float32)
+    est.joint_filter(j3b, dim=3, timestamp=T0 + 0.04)
+    assert np.all(np.abs(j3b - keep) <= 1.5) and not np.array_equal(j3b, keep + np.float32(1.5))   # smoothed towards the past
+    est.close()
+
+
+@pytest.mark.parametrize("promo", [0, 1])
+def test_joint_filter_3d_chain_vs_reference_recording(weights, promo):
+    """The 3-D bank through joint_filter over a float32 sequence, against the float32-fed OneEuro chain the oracle runs
+    inside vo_est_postprocess (bit-exact against the imported reference, tests/golden/glue_*.npz): planted maps whose
+    read-off is known make the oracle's raw 3-D joints available, so both sides filter the same float32 inputs."""
+    from vnect_amd import _native
+    from tests import helpers
+    import oracle
+    h = _native.Handle([1.0], numpy_promotion=promo)
+    h.set_weights(weights)
+    h.finalize()
+    ref = oracle.OracleEstimator(scales=[1.0], nep50=bool(promo))
+    t = T0
+    for k in range(25):
+        t += 1 / 30 + 0.004 * ((k * 3) % 4)
+        maps = helpers.synth_maps(1200 + k, 1)
+        # oracle: full post-processing (2-D filter, read-off at the filtered joints, 3-D filter)
+        o2, o3 = ref.postprocess(maps, t, t + 0.0005)
+        # GPU, piecewise through the public surface: raw joints from a throw-away handle state, then the two banks by hand
+        avg = oracle.merge_scales(maps, [1.0])
+        raw2 = oracle.extract_2d(avg[0])
+        f2 = h.joint_filter(2, raw2, False, t)
+        assert np.array_equal(f2, o2), k                               # un-mapping is the identity here (scaler 1, offsets 0)
+        raw3 = oracle.extract_3d(f2, avg[1], avg[2], avg[3])           # float32, root-relative (utils.py:178-219)
+        f3 = h.joint_filter(3, raw3, True, t + 0.0005).astype(np.float32)
+        assert np.array_equal(f3, o3), k
+    h.close()
+
+
+def test_timestamp_errors_mirror_reference(weights):
+    """t == previous -> ZeroDivisionError (OneEuroFilter.py:66); t < previous -> ValueError (negative freq drives alpha out of
+    (0, 1], OneEuroFilter.py:19-23).  Either way the call is rejected BEFORE any state changes: the next valid frame equals
+    what an estimator that never saw the bad call returns."""
+    from tests import helpers
+    a, b = _est(weights, scales=[1.0]), _est(weights, scales=[1.0])
+    f = [helpers.synth_frame(60 + k, smooth=True) for k in range(3)]
+    a(f[0], timestamp=10.0), b(f[0], timestamp=10.0)
+    with pytest.raises(ZeroDivisionError):
+        a(f[1], timestamp=10.0)
+    with pytest.raises(ValueError):
+        a(f[1], timestamp=9.5)
+    with pytest.raises(ValueError):
+        a.joint_filter(np.zeros((21, 2)), dim=2, timestamp=9.0)
+    with pytest.raises(ValueError):
+        a.postprocess(helpers.synth_maps(1, 1), timestamp=(9.0, 11.0))
+    x2, x3 = a(f[1], timestamp=10.04)
+    y2, y3 = b(f[1], timestamp=10.04)
+    assert np.array_equal(x2, y2) and np.array_equal(x3, y3)
+    # timestamp 0.0 is "no timestamp" (truthiness test, OneEuroFilter.py:65): accepted after any time
+    a(f[2], timestamp=0.0)
+    a.close(), b.close()
+
+
+# ------------------------------------------------------------------------------------------ weight files (row f2)
+def test_weight_files_pickle_and_npz(weights, oracle_net, tmp_path):
+    """VNectEstimator(weights=path) with the reference's params.pkl layout (caffe2pkl.py:83-88: one pickled dict) and with
+    an .npz of the same keys: maps bit-identical to the dict-fed handle and within the fp32 tolerance of the oracle; files
+    with a missing or mis-shaped array are refused like the reference's load_weights (vnect_model.py:219-236 KeyErrors)."""
+    import oracle
+    from tests import helpers
+    pkl, npz = tmp_path / "params.pkl", tmp_path / "params.npz"
+    with open(pkl, "wb") as f:
+        pickle.dump({k: np.asarray(v) for k, v in weights.items()}, f)
+    np.savez(npz, **weights)
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(808, smooth=True), [1.0])
+    ref = oracle_net.forward(batch)
+    base = _est(weights, scales=[1.0])
+    want = base.forward(batch)
+    assert np.abs(want - ref).max() <= 1e-4 * np.abs(ref).max()
+    for path in (pkl, npz):
+        est = _est(str(path), scales=[1.0])
+        assert np.array_equal(est.forward(batch), want), path.name
+        j2, j3 = est(helpers.synth_frame(809, 300, 400, smooth=True), timestamp=5.0)
+        b2, b3 = base(helpers.synth_frame(809, 300, 400, smooth=True), timestamp=5.0)
+        base.reset()
+        assert np.array_equal(j2, b2) and np.array_equal(j3, b3)
+        est.close()
+    base.close()
+    bad = dict(weights)
+    del bad["res4c_branch2b/weights"]
+    np.savez(tmp_path / "missing.npz", **bad)
+    with pytest.raises(ValueError, match="res4c_branch2b/weights"):
+        _est(str(tmp_path / "missing.npz"), scales=[1.0])
+    bad = dict(weights)
+    bad["res5c_branch1a/kernel"] = np.zeros((4, 4, 256, 63), np.float32)   # Cin/Cout swapped
+    with open(tmp_path / "shape.pkl", "wb") as f:
+        pickle.dump(bad, f)
+    with pytest.raises(ValueError, match="res5c_branch1a/kernel"):
+        _est(str(tmp_path / "shape.pkl"), scales=[1.0])
+    # the C ABI itself refuses an incomplete set too (a host that bypasses weights.py)
+    from vnect_amd import _native
+    h = _native.Handle([1.0])
+    h.set_weights({k: v for k, v in weights.items() if k != "conv1/biases"})
+    with pytest.raises(_native.VnectError, match="conv1/biases"):
+        h.finalize()
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ person box (row f3)
+def test_init_box_on_the_gpu_vs_oracle(weights, oracle_net):
+    """runner.init_box with a real estimator: the probe over the whole frame (the reference's no-detection rectangle,
+    hog_box.py:28-29) must give the box the oracle-driven equivalent gives, and must not leave filter state behind: the first
+    tracked frame is bit-identical to a fresh estimator's."""
+    import oracle
+    from vnect_amd import runner
+    scales = BASELINE_SCALES
+    est, fresh = _est(weights, scales=scales), _est(weights, scales=scales)
+    frame = next(runner.synthetic_stream(5, 1, 420, 560))
+
+    class OracleEst:  # the oracle behind the estimator call surface init_box uses
+        def __init__(self):
+            self.o = oracle.OracleEstimator(scales=scales, net=oracle_net)
+
+        def __call__(self, img, timestamp=None):
+            return self.o(np.ascontiguousarray(img), timestamp, timestamp)
+
+        def reset(self):
+            self.o.reset()
+
+    box = runner.init_box(est, frame, timestamp=3.0)
+    ref_est = OracleEst()
+    ref_box = runner.init_box(ref_est, frame, timestamp=3.0)
+    # the box is arithmetic on the arg-max joints: equal unless a heat-map tie moved an extreme joint (then the GPU's
+    # joints must still satisfy the tie rule; checked by recomputing the box from them)
+    j2, _ = fresh(frame, timestamp=3.0)
+    fresh.reset()
+    assert box == runner.bbox_update(j2, 560, 420)
+    r2, _ = ref_est(frame, timestamp=3.0)
+    ref_est.reset()
+    if np.array_equal(j2, r2):
+        assert box == ref_box
+    else:
+        batch, _, _ = oracle.gen_input_batch(frame, scales)
+        avg = oracle.merge_scales(oracle_net.forward(batch), scales)[0]
+        sc = 368.0 / 560
+        for j in np.nonzero(np.any(j2 != r2, axis=1))[0]:
+            up = oracle.resize(np.ascontiguousarray(avg[:, :, j]), 8.0)
+            y, x = int(round(j2[j, 0] * sc + (184 - int(round(420 * sc)) // 2))), int(round(j2[j, 1] * sc))
+            assert up[min(max(y, 0), 367), min(max(x, 0), 367)] >= up.max() - 1e-4 * np.abs(avg).max(), j
+    assert 0 <= box[0] and 0 <= box[1] and box[0] + box[2] <= 560 and box[1] + box[3] <= 420 and box[2] >= 1 and box[3] >= 1
+    # filter-reset property: the frame after the probe is an unfiltered first frame
+    x, y, w, h = box
+    crop = frame[y:y + h, x:x + w]
+    a2, a3 = est(crop, timestamp=4.0)
+    b2, b3 = fresh(crop, timestamp=4.0)
+    assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+    est.close(), fresh.close()
+
+
+# ------------------------------------------------------------------------------------------ static gen_input_batch (a10)
+def test_static_gen_input_batch_needs_no_weights(weights):
+    """VNectEstimator.gen_input_batch is a @staticmethod in the reference (estimator.py:70-81): it runs on a pre-processing-only
+    handle (no weights, no launch plan) and is bit-exact against the oracle; such a handle refuses everything else."""
+    import oracle
+    from tests import helpers
+    from vnect_amd import VNectEstimator, _native
+    frame = helpers.synth_frame(31, 300, 500, smooth=True)
+    for scales in ([1, 0.85, 0.7], [1.0, 0.6]):
+        b, s, off = VNectEstimator.gen_input_batch(frame, 368, scales)
+        rb, rs, roff = oracle.gen_input_batch(frame, scales)
+        assert np.array_equal(b, rb) and s == rs and off == roff
+    flipped = frame[::-1, ::-1]   # negative strides: the reference takes any ndarray
+    b, _, _ = VNectEstimator.gen_input_batch(flipped, 368, [1.0])
+    rb, _, _ = oracle.gen_input_batch(np.ascontiguousarray(flipped), [1.0])
+    assert np.array_equal(b, rb)
+    h = _native.Handle([1.0], preprocess_only=True)
+    with pytest.raises(_native.VnectError):
+        h.finalize()
+    with pytest.raises(_native.VnectError):
+        h.infer(frame, 1.0, 1.0)
+    with pytest.raises(_native.VnectError):
+        h.forward(np.zeros((1, 368, 368, 3), np.float32))
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ boundary robustness
+def test_no_exception_crosses_the_abi(weights):
+    """include/vnect_abi.h promises codes, never C++ exceptions.  A weight whose shape multiplies out to more elements than
+    any allocation can hold makes std::vector throw inside vnect_set_weight: the call must return VNECT_E_INTERNAL (or
+    VNECT_E_ARG), leave a message, and leave the handle usable."""
+    from vnect_amd import _native
+    L = _native.lib()
+    h = _native.Handle([1.0])
+    shp = (C.c_int64 * 2)(1 << 40, 1 << 20)      # 2^60 floats
+    one = np.zeros(4, np.float32)
+    rc = L.vnect_set_weight(h._h, b"conv1/biases", one.ctypes.data_as(C.POINTER(C.c_float)), shp, 2)
+    assert rc in (_native.E_INTERNAL, _native.E_ARG)
+    assert L.vnect_last_error(h._h)
+    h.set_weights(weights)   # still usable
+    h.finalize()
+    out = h.forward(np.zeros((1, 368, 368, 3), np.float32))
+    assert np.all(np.isfinite(out))
+    h.close()

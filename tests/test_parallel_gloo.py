@@ -58,3 +58,85 @@ def test_world_one_needs_no_process_group():
         for k, v in saved.items():
             if v is not None:
                 os.environ[k] = v
+
+
+PYRAMID_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+from vnect_amd.parallel import Group, PyramidJob, stream_seed
+from tests import helpers
+
+class StubHandle:
+    # the pyramid part of _native.Handle's surface, recording what the host logic does with it
+    log = []
+    def __init__(self, rank, world, exchange):
+        self.rank, self.world, self.exchange = rank, world, exchange
+        self.frames, self.inferred, self.connected = {}, 0, None
+    @staticmethod
+    def comm_unique_id():
+        StubHandle.log.append("uid")
+        return bytes(range(128))
+    def comm_init(self, rank, world, uid):
+        assert (rank, world) == (self.rank, self.world) and uid == bytes(range(128))
+        self.connected = "rccl"
+    def p2p_export(self):
+        return bytes([self.rank]) * 128
+    def p2p_init(self, rank, world, blobs):
+        assert (rank, world) == (self.rank, self.world) and len(blobs) == world
+        assert [b[0] for b in blobs] == list(range(world)) and all(len(b) == 128 for b in blobs)
+        self.connected = "p2p"
+    def upload_frame(self, slot, frame):
+        self.frames[slot] = int(frame.sum())
+    def infer_resident(self, slot, t2d, t3d):
+        assert self.connected and slot in self.frames and t3d > t2d
+        self.inferred += 1
+        return ("joints", slot)
+
+g = Group("gloo")
+assert g.world == 3
+scales = [1.0, 0.8, 0.6]
+res = {}
+for exchange in ("rccl", "p2p"):
+    StubHandle.log = []
+    job = PyramidJob(g, scales, StubHandle, exchange)
+    assert job.scale == scales[g.rank] and job.handle.connected == exchange
+    # only rank 0 makes the communicator id; everybody receives it
+    assert (StubHandle.log == ["uid"]) == (g.rank == 0 and exchange == "rccl")
+    # every rank uploads the SAME stream 0
+    job.upload([helpers.synth_frame(stream_seed(0, k), 16, 16) for k in range(4)])
+    g.barrier()
+    (last, t) = job.run(10, 4, 100.0)          # the timed loop ...
+    (last, t) = job.run(5, 4, t)               # ... and the profiling loop: EVERY rank takes part in both
+    assert last == ("joints", 0) and job.handle.inferred == 15 and abs(t - (100.0 + 15 / 30)) < 1e-9
+    res[exchange] = [job.handle.frames[k] for k in range(4)]
+    m = g.max_over_ranks(1.0 + g.rank)
+    assert m == 3.0
+try:
+    PyramidJob(g, [1.0, 0.7], StubHandle)
+    raise SystemExit("a 2-scale pyramid on 3 ranks must be refused")
+except ValueError:
+    pass
+print(json.dumps({"rank": g.rank, "frames": res}), flush=True)
+g.close()
+"""
+
+
+def test_three_rank_pyramid_host_logic_gloo(tmp_path):
+    """bench.py --pyramid's host side (vnect_amd.parallel.PyramidJob) with world_size 3 over gloo and a stub handle: rank -> scale
+    mapping, the ncclUniqueId made by rank 0 and broadcast, the all-gather of the p2p export blobs, the same stream on every
+    rank, and every rank taking part in the timed AND the profiling loop (each inference contains the exchange)."""
+    script = tmp_path / "pyramid_worker.py"
+    script.write_text(PYRAMID_WORKER % ROOT)
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29519")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(eval(o.strip().splitlines()[-1]))
+    assert {o["rank"] for o in outs} == {0, 1, 2}
+    assert outs[0]["frames"] == outs[1]["frames"] == outs[2]["frames"]   # one stream, seen by all ranks

@@ -14,7 +14,9 @@ LIB_PATH = os.environ.get("VNECT_LIB") or os.path.join(_HERE, "lib", "libvnect_h
 _lib = None
 
 MAX_SCALES = 8
-OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM, E_TIMEORDER, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
+ABI_VERSION = 2
+XCHG_RCCL, XCHG_P2P = 0, 1
 FP32, BF16 = 0, 1
 
 
@@ -29,7 +31,8 @@ class Config(C.Structure):
                 ("scales", C.c_double * MAX_SCALES), ("precision", C.c_int32), ("paper_res2c", C.c_int32),
                 ("use_graph", C.c_int32), ("numpy_promotion", C.c_int32), ("max_frame_bytes", C.c_int32),
                 ("num_frame_slots", C.c_int32), ("pyramid_nranks", C.c_int32), ("pyramid_rank", C.c_int32),
-                ("keep_activations", C.c_int32), ("lanes", C.c_int32)]
+                ("keep_activations", C.c_int32), ("lanes", C.c_int32), ("preprocess_only", C.c_int32),
+                ("exchange", C.c_int32)]
 
 
 class Timings(C.Structure):
@@ -62,6 +65,7 @@ SYMBOLS = {
     "vnect_infer_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, _f64p, _f32p]),
     "vnect_submit_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
     "vnect_collect": (C.c_int, [_H, _f64p, _f32p]),
+    "vnect_joint_filter": (C.c_int, [_H, C.c_int, _f64p, C.c_int, C.c_double, _f64p]),
     "vnect_reset_filters": (C.c_int, [_H]),
     "vnect_read_activation": (C.c_int, [_H, C.c_char_p, _f32p, C.c_int64, _i32p]),
     "vnect_set_profiling": (C.c_int, [_H, C.c_int]),
@@ -71,6 +75,8 @@ SYMBOLS = {
     "vnect_get_layer_stamps": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint64)]),
     "vnect_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vnect_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "vnect_comm_p2p_export": (C.c_int, [_H, C.c_void_p]),
+    "vnect_comm_p2p_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
 }
 
 
@@ -93,7 +99,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
             fn.restype, fn.argtypes = res, args
-        if L.vnect_abi_version() != 1:
+        if L.vnect_abi_version() != ABI_VERSION:
             raise ImportError("libvnect_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -107,7 +113,8 @@ class Handle:
     """Thin RAII wrapper over vnect_handle; every method maps 1:1 to a C entry point."""
 
     def __init__(self, scales, device=0, precision=FP32, paper_res2c=False, use_graph=True, numpy_promotion=0,
-                 max_frame_bytes=0, num_frame_slots=0, pyramid=None, keep_activations=False, lanes=1):
+                 max_frame_bytes=0, num_frame_slots=0, pyramid=None, keep_activations=False, lanes=1,
+                 preprocess_only=False, exchange=XCHG_RCCL):
         L = lib()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -119,6 +126,8 @@ class Handle:
         cfg.numpy_promotion, cfg.max_frame_bytes, cfg.num_frame_slots = numpy_promotion, max_frame_bytes, num_frame_slots
         cfg.lanes = int(lanes)  # 2: submit_resident/collect overlap two frames on two lanes
         cfg.keep_activations = int(keep_activations)  # True: activation(name) can return inner layers (tests)
+        cfg.preprocess_only = int(preprocess_only)    # gen_input_batch only: no weights, no launch plan
+        cfg.exchange = int(exchange)                  # pyramid sharding: XCHG_RCCL (ncclAllGather) or XCHG_P2P (peer writes)
         if pyramid is not None:  # (rank, nranks): this handle runs one scale of the pyramid (vnect_comm_init)
             cfg.pyramid_rank, cfg.pyramid_nranks = int(pyramid[0]), int(pyramid[1])
         h = _H()
@@ -232,6 +241,28 @@ class Handle:
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
         self._ck(lib().vnect_comm_init(self._h, rank, nranks, buf))
 
+    def joint_filter(self, dim, values, values_are_f32, t):
+        """The handle's 2-D / 3-D OneEuro bank over (21, dim) values at timestamp t -> filtered float64 array."""
+        vin = np.ascontiguousarray(values, dtype=np.float64)
+        if vin.shape != (21, dim):
+            raise ValueError("joints must be (21, %d)" % dim)
+        out = np.empty((21, dim), np.float64)
+        self._ck(lib().vnect_joint_filter(self._h, dim, _ptr(vin, _f64p), int(values_are_f32), float(t), _ptr(out, _f64p)))
+        return out
+
+    def p2p_export(self):
+        """128-byte description of this rank's exchange block (exchange=XCHG_P2P); give every rank everybody's."""
+        buf = (C.c_char * 128)()
+        self._ck(lib().vnect_comm_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_init(self, rank, nranks, blobs):
+        raw = b"".join(blobs)
+        if len(raw) != 128 * nranks:
+            raise ValueError("p2p_init needs one 128-byte blob per rank")
+        buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+        self._ck(lib().vnect_comm_p2p_init(self._h, rank, nranks, buf))
+
     def reset_filters(self):
         self._ck(lib().vnect_reset_filters(self._h))
 
@@ -274,6 +305,8 @@ def _as_frame(img):
     img = np.asarray(img)
     if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
         raise ValueError("frame must be a uint8 (H, W, 3) BGR array")
-    if img.strides[2] != 1 or img.strides[1] != 3:
-        img = np.ascontiguousarray(img)  # row stride may stay arbitrary (crops of a larger frame)
+    # A positive row stride may stay arbitrary (crops of a larger frame are passed by stride, no copy); anything else the
+    # reference accepts -- flipped views (negative strides), broadcast rows (stride 0), channel-swapped views -- is copied
+    if img.strides[2] != 1 or img.strides[1] != 3 or img.strides[0] < img.shape[1] * 3:
+        img = np.ascontiguousarray(img)
     return img

@@ -173,4 +173,31 @@ hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const
 hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
                          const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st);
 
+// ---- pyramid sharding: the exchange by peer writes (SURVEY 8e "plain peer writes ... into the gather buffer") -----------
+// Every rank owns one exchange block [2 parities][nranks slots][XCHG_MAPS floats] + flags[2][8] (u32, one 128-B line per
+// parity), reachable by every peer (IPC-mapped across processes, hipDeviceEnablePeerAccess inside one).  One launch per frame:
+// workgroup (peer p, chunk c) stores chunk c of this rank's maps into slot `rank` of p's block (16-B system-scope
+// write-through stores over xGMI), the last chunk-workgroup per peer publishes flags_p[parity][rank] = seq behind a
+// system-scope release; then the same workgroup waits (bounded) for flags_local[parity][p] == seq and copies p's slot from the
+// local block into the handle's plain gather buffer, which the post-processing kernels read.  Two parities: a rank can run at
+// most one frame ahead of a peer (it needs the peer's maps of frame k to finish frame k).
+constexpr int XCHG_MAPS = HM * HM * MAPC;   // 177 744 floats = 710 976 B per rank and frame
+constexpr int XCHG_CHUNKS = 8;              // workgroups per peer
+constexpr size_t XCHG_FLAG_OFF = (size_t)2 * 8 * XCHG_MAPS * sizeof(float);  // byte offset of the flags in an exchange block
+constexpr size_t XCHG_BYTES = XCHG_FLAG_OFF + 2 * 128;
+struct XchgArgs {
+    const float* src;        // this rank's (46,46,84) maps
+    char* block[8];          // every rank's exchange block as THIS device addresses it (block[rank] is the local one)
+    float* gather;           // local (nranks, 46,46,84): what the merge / arg-max / joints kernels read
+    unsigned* tickets;       // local, [8]: chunk-workgroups of a peer that have finished their stores
+    int* status;             // device-mapped pinned host word: set to 1 if a peer's flag did not arrive within the bound
+    int rank, nranks, parity;
+    unsigned seq;            // frame sequence number (> 0), the flag value
+    unsigned spin_limit;     // polls before giving up (each ~1 us)
+};
+hipError_t launch_exchange(const XchgArgs& a, hipStream_t st);
+
+// VNectEstimator.joint_filter alone: bank `dim` of fb over NJ * dim values (float64 carriers; f32vals: they are float32 scalars)
+hipError_t launch_filter(FilterBank* fb, int dim, bool f32vals, int nep50, double t, const double* in, double* out, hipStream_t st);
+
 }  // namespace vnect

@@ -364,4 +364,96 @@ hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeT
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The pyramid exchange by peer writes (kernels.h: XchgArgs).  Correctness never depends on timing: a slot is read only after
+// its flag carries this frame's sequence number, the flag is written after a system-scope release behind ALL of the slot's
+// stores (last-arriver ticket over the 8 chunk-workgroups), and every wait is bounded.
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sys(f32x4g* p, f32x4g v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");  // system scope, write-through
+#else
+    *p = v;
+#endif
+}
+// system-scope 16-byte load (sc0 sc1: served by memory, not by a cache line another agent may have made stale); a buffer load
+// so that the compiler tracks its completion itself and several can be in flight
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4g load_sys(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 1 | 16));
+}
+#endif
+__global__ __launch_bounds__(256) void exchange_kernel(const XchgArgs a)
+{
+    const int p = blockIdx.x / XCHG_CHUNKS, c = blockIdx.x % XCHG_CHUNKS, tid = threadIdx.x;
+    constexpr int N4 = XCHG_MAPS / 4;                       // 44 436 16-byte units per slot
+    constexpr int PER = (N4 + XCHG_CHUNKS - 1) / XCHG_CHUNKS;
+    const int u0 = c * PER, u1 = u0 + PER < N4 ? u0 + PER : N4;
+    const f32x4g* src = (const f32x4g*)a.src;
+    // ---- push: chunk c of my maps -> slot `rank` of peer p's block
+    f32x4g* dst = (f32x4g*)(a.block[p] + ((size_t)a.parity * 8 + a.rank) * XCHG_MAPS * sizeof(float));
+    for (int u = u0 + tid; u < u1; u += 256) store_sys(dst + u, src[u]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int ok;
+    if (tid == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: the stores above are visible to p before the flag can be
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(a.tickets + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == XCHG_CHUNKS - 1) {  // every chunk of this slot has been stored and released: publish
+            __hip_atomic_store(a.tickets + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* flag = (unsigned*)(a.block[p] + XCHG_FLAG_OFF + (size_t)a.parity * 128) + a.rank;
+            __hip_atomic_store(flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // ---- pull: wait for peer p's slot in MY block
+        const unsigned* mine = (const unsigned*)(a.block[a.rank] + XCHG_FLAG_OFF + (size_t)a.parity * 128) + p;
+        unsigned seen = 0, spins = 0;
+        // relaxed polls (an acquire per poll would invalidate this CU's cache every time), ONE acquire once the flag matches
+        while ((seen = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != a.seq && spins < a.spin_limit) {
+            __builtin_amdgcn_s_sleep(32);
+            spins++;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        ok = seen == a.seq;
+        if (!ok) *a.status = 1;
+    }
+    __syncthreads();
+    if (!ok) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t from = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.block[a.rank] + ((size_t)a.parity * 8 + p) * XCHG_MAPS * sizeof(float)), 0, XCHG_MAPS * 4, 0x00020000);
+    f32x4g* to = (f32x4g*)(a.gather + (size_t)p * XCHG_MAPS);
+    for (int u = u0 + tid; u < u1; u += 256) to[u] = load_sys(from, u * 16);
+#endif
+}
+hipError_t launch_exchange(const XchgArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL(exchange_kernel, dim3(a.nranks * XCHG_CHUNKS), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// VNectEstimator.joint_filter (estimator.py:83-95) on its own: the handle's filter bank applied to caller-supplied joints,
+// one thread per filter.  Bank `dim` (2: 21 x 2 filters, 3: 21 x 3); f32vals: the values are numpy float32 scalars (what
+// the reference feeds the 3-D bank, estimator.py:91-93), so numpy's scalar promotion decides the arithmetic (oef_f32);
+// otherwise plain float64 (oef_f64).  in / out may be device-mapped pinned host memory.
+__global__ __launch_bounds__(64) void filter_kernel(FilterBank* fb, int dim, int f32vals, int nep50, double t,
+                                                    const double* __restrict__ in, double* __restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= NJ * dim) return;
+    Filt* fp = dim == 2 ? &fb->f2[i >> 1][i & 1] : &fb->f3[i / 3][i % 3];
+    Filt f = *fp;
+    out[i] = f32vals ? (double)oef_f32(f, (float)in[i], t, nep50) : oef_f64(f, in[i], t);
+    *fp = f;
+}
+hipError_t launch_filter(FilterBank* fb, int dim, bool f32vals, int nep50, double t, const double* in, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(filter_kernel, dim3(1), dim3(64), 0, st, fb, dim, (int)f32vals, nep50, t, in, out);
+    return hipGetLastError();
+}
+
 }  // namespace vnect

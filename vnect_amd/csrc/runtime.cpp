@@ -1,6 +1,7 @@
 // runtime.cpp -- host side of libvnect_hip.so: handle, weight packing, launch plan, HIP graph, C ABI.
 // See include/vnect_abi.h for the boundary and the reference lines each entry point replaces.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,7 +19,8 @@ using namespace vnect;
 
 namespace {
 
-std::string g_create_error = "";
+// message of the last vnect_create failure on THIS thread (handles are created from several threads / processes)
+thread_local std::string g_create_error = "";
 
 struct HostArray {
     std::vector<float> d;
@@ -60,6 +62,7 @@ struct vnect_handle {
     int Snet = 0;   // images this handle pushes through the conv stack: S, or 1 when pyramid-sharded
     std::string err;
     bool finalized = false;
+    bool pre_only = false;  // vnect_config::preprocess_only: the input batch buffer and the resize tables, nothing else
     bool bf16 = false;  // VNECT_BF16: bf16 activations + weights, fp32 accumulate; final maps and post-processing stay fp32/f64
     hipStream_t st = nullptr;
     std::map<std::string, HostArray> weights;
@@ -97,6 +100,8 @@ struct vnect_handle {
     UpTab* d_up = nullptr;
     ArgPartial* d_part = nullptr;
     FilterBank* d_fb = nullptr;
+    double* h_filt = nullptr;      // pinned, device-mapped: vnect_joint_filter's values in ([0, 64)) and out ([64, 128))
+    double* h_filt_dev = nullptr;
     JointsOut* h_out[RING] = {};   // pinned, device-mapped: joints_kernel writes a frame's results straight into its ring slot
     JointsOut* h_out_dev[RING] = {};  // the same slots as the device addresses them
     hipEvent_t done[RING] = {};
@@ -113,7 +118,6 @@ struct vnect_handle {
     hipGraphExec_t pgexec = nullptr;
     unsigned long long* d_prof = nullptr;       // [layer][2] device stamps (100 MHz)
     unsigned long long* h_prof = nullptr;       // pinned read-back
-    unsigned long long* h_prof_init = nullptr;  // pinned {~0, 0} pattern
     unsigned long long* d_prof_end = nullptr;   // [128 layers][PROF_WGS] per-workgroup end stamps of the profiling twin
     unsigned long long* h_prof_end = nullptr;   // pinned read-back
     // profiling
@@ -126,15 +130,42 @@ struct vnect_handle {
     void* comm = nullptr;
     bool sharded = false;
     float* gather = nullptr;  // (S,46,46,84): all ranks' maps
+    // exchange by peer writes (vnect_config::exchange == VNECT_XCHG_P2P; kernels.h: XchgArgs)
+    char* xblock = nullptr;            // this rank's exchange block (fine-grained device memory, IPC-exported)
+    char* xpeer[VNECT_MAX_SCALES] = {};  // every rank's block as this device addresses it; [rank] == xblock
+    bool xopened[VNECT_MAX_SCALES] = {};  // xpeer[r] came from hipIpcOpenMemHandle (close it on destroy)
+    bool p2p_ready = false;
+    unsigned* xtickets = nullptr;
+    int* h_xstatus = nullptr;          // pinned, device-mapped: a peer's flag did not arrive within the bound
+    int* h_xstatus_dev = nullptr;
 };
 
 namespace {
 
-int fail(vnect_handle* h, int code, const std::string& msg)
+int fail(vnect_handle* h, int code, const std::string& msg) noexcept
 {
-    if (h) h->err = msg;
-    else g_create_error = msg;
+    try {
+        if (h) h->err = msg;
+        else g_create_error = msg;
+    } catch (...) {  // out of memory while recording the message: the code still goes back
+    }
     return code;
+}
+
+// No C++ exception crosses the ABI: every extern "C" body runs inside this guard (std::vector / std::string / std::map / new
+// can throw std::bad_alloc or std::length_error on a hostile size).
+template <typename F>
+int guarded(vnect_handle* const* hp, F&& body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(hp ? *hp : nullptr, VNECT_E_INTERNAL, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(hp ? *hp : nullptr, VNECT_E_INTERNAL, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(hp ? *hp : nullptr, VNECT_E_INTERNAL, "internal error");
+    }
 }
 
 #define HIPCK(h, expr)                                                                          \
@@ -901,15 +932,28 @@ int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
     return VNECT_OK;
 }
 
+// OneEuroFilter.py:65-66: `if self.__lasttime and timestamp: self.__freq = 1.0 / (timestamp - self.__lasttime)`.
+//   t == last  -> ZeroDivisionError (VNECT_E_TIMESTAMP);
+//   t <  last  -> freq < 0, so alpha = 1 / (1 + tau * freq) leaves (0, 1] and LowPassFilter.__setAlpha raises ValueError
+//                 (OneEuroFilter.py:19-23) -> VNECT_E_TIMEORDER.
+// Nothing is committed here: the reference would leave half-updated filters behind its exception, this path rejects the call
+// before any state changes, and the host-side copy of the last timestamps moves only after the frame has been enqueued.
 int check_time(vnect_handle* h, double t2d, double t3d)
 {
-    // OneEuroFilter.py:65-66: freq = 1/(t - lasttime) when both are truthy -> ZeroDivisionError on equal stamps
-    if (h->have2 && h->last2 != 0.0 && t2d != 0.0 && t2d == h->last2)
-        return fail(h, VNECT_E_TIMESTAMP, "t2d equals the previous 2-D filter timestamp");
-    if (h->have3 && h->last3 != 0.0 && t3d != 0.0 && t3d == h->last3)
-        return fail(h, VNECT_E_TIMESTAMP, "t3d equals the previous 3-D filter timestamp");
-    h->have2 = h->have3 = true, h->last2 = t2d, h->last3 = t3d;
+    if (h->have2 && h->last2 != 0.0 && t2d != 0.0) {
+        if (t2d == h->last2) return fail(h, VNECT_E_TIMESTAMP, "t2d equals the previous 2-D filter timestamp");
+        if (t2d < h->last2) return fail(h, VNECT_E_TIMEORDER, "t2d is earlier than the previous 2-D filter timestamp");
+    }
+    if (h->have3 && h->last3 != 0.0 && t3d != 0.0) {
+        if (t3d == h->last3) return fail(h, VNECT_E_TIMESTAMP, "t3d equals the previous 3-D filter timestamp");
+        if (t3d < h->last3) return fail(h, VNECT_E_TIMEORDER, "t3d is earlier than the previous 3-D filter timestamp");
+    }
     return VNECT_OK;
+}
+// `self.__lasttime = timestamp` runs on every call, also with timestamp 0.0 / None
+void commit_time(vnect_handle* h, double t2d, double t3d)
+{
+    h->have2 = h->have3 = true, h->last2 = t2d, h->last3 = t3d;
 }
 
 int reset_filters_impl(vnect_handle* h)
@@ -931,6 +975,34 @@ int reset_filters_impl(vnect_handle* h)
     h->have2 = h->have3 = false;
     return VNECT_OK;
 }
+
+// ---- roctx ranges (SURVEY 5 aux: tracing).  Opt-in with VNECT_ROCTX=1; libroctx64 is dlopen'ed, so nothing links it. -----
+// The ranges bracket the ENQUEUE of each stage of a frame on the host thread (pre-processing, conv stack + merge/arg-max,
+// filters + read-off); rocprofv3 --marker-trace shows them above the kernel rows of the same stream.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+} g_roctx;
+void roctx_load()
+{
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    const char* e = getenv("VNECT_ROCTX");
+    if (!e || !atoi(e)) return;
+    void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);  // what rocprofv3 --marker-trace listens to
+    if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+    g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+    if (!g_roctx.push || !g_roctx.pop) g_roctx.push = nullptr, g_roctx.pop = nullptr;
+}
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { if (g_roctx.push) g_roctx.push(name); }
+    ~RoctxRange() { if (g_roctx.pop) g_roctx.pop(); }
+};
 
 // ---- RCCL, opened lazily so single-GPU use never loads it -----------------------------------------------
 typedef struct { char internal[128]; } nccl_uid;
@@ -957,28 +1029,41 @@ bool load_rccl()
     return false;
 }
 
-// rank r's (46,46,84) maps -> slot r of the (S,46,46,84) gather buffer on every rank (the one exchange of SURVEY 8e)
-int all_gather_maps(vnect_handle* h)
+// rank r's (46,46,84) maps -> slot r of the (S,46,46,84) gather buffer on every rank (the one exchange of SURVEY 8e),
+// by ncclAllGather or by peer writes (kernels.h: XchgArgs).  `seq` numbers the frame (the p2p flag value).
+int exchange_maps(vnect_handle* h, unsigned long long seq)
 {
-    if (!h->comm) return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init before inference");
     const Tensor& t = h->tensors[h->t_out];
+    if (h->cfg.exchange == VNECT_XCHG_P2P) {
+        if (!h->p2p_ready) return fail(h, VNECT_E_STATE, "pyramid-sharded handle (p2p): call vnect_comm_p2p_init before inference");
+        XchgArgs a{};
+        a.src = t.d, a.gather = h->gather, a.tickets = h->xtickets, a.status = h->h_xstatus_dev;
+        for (int r = 0; r < h->S; r++) a.block[r] = h->xpeer[r];
+        a.rank = h->cfg.pyramid_rank, a.nranks = h->S, a.parity = (int)(seq & 1), a.seq = (unsigned)(seq + 1);
+        const char* lim = getenv("VNECT_XCHG_SPINS");  // polls (~1 us each) before a missing peer fails the frame; default ~2 s
+        a.spin_limit = lim && atoi(lim) > 0 ? (unsigned)atoi(lim) : 2000000u;
+        HIPCK(h, launch_exchange(a, h->st));
+        return VNECT_OK;
+    }
+    if (!h->comm) return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init before inference");
     const int rc = p_ncclAllGather(t.d, h->gather, (size_t)HM * HM * MAPC, 7 /* ncclFloat32 */, h->comm, h->st);
     if (rc != 0)
         return fail(h, VNECT_E_COMM, std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"));
     return VNECT_OK;
 }
+bool comm_ready(const vnect_handle* h) { return h->cfg.exchange == VNECT_XCHG_P2P ? h->p2p_ready : h->comm != nullptr; }
 
-// The part of a frame without per-frame arguments (what the hipGraph holds): conv stack, [all-gather], merge + arg-max.
-// The pyramid kernel before it and the joints kernel after it take the frame's arguments by value and are launched
-// around the graph.
+// The part of a frame without per-frame arguments (what the hipGraph holds): conv stack, merge + arg-max.  The pyramid kernel
+// before it and the joints kernel after it take the frame's arguments by value and are launched around the graph.  A
+// pyramid-sharded handle's graph ends with the conv stack: the exchange (whose flag value / parity change every frame) and the
+// merge + arg-max launch behind it are eager (two captured parts around the exchange -- the
+// second part is the single arg-max launch, which gains nothing from a graph of its own).
 int run_frame_kernels(vnect_handle* h, bool timed)
 {
     const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
     int rc = run_network(h, timed);
     if (rc) return rc;
-    if (h->sharded && (rc = all_gather_maps(h))) return rc;
-    rc = run_argmax(h);
-    if (rc) return rc;
+    if (!h->sharded && (rc = run_argmax(h))) return rc;
     if (timed) {
         HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
         HIPCK(h, hipMemcpyAsync(h->h_prof_end, h->d_prof_end, h->layers.size() * PROF_WGS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
@@ -992,7 +1077,7 @@ int build_graph(vnect_handle* h)
     if (h->graph) hipGraphDestroy(h->graph), h->graph = nullptr;
     if (h->pgexec) hipGraphExecDestroy(h->pgexec), h->pgexec = nullptr;
     if (h->pgraph) hipGraphDestroy(h->pgraph), h->pgraph = nullptr;
-    if (!h->cfg.use_graph || h->sharded) return VNECT_OK;  // sharded: the collective sits between net and post
+    if (!h->cfg.use_graph) return VNECT_OK;
     HIPCK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
     int rc = run_frame_kernels(h, false);
     hipError_t e = hipStreamEndCapture(h->st, &h->graph);
@@ -1076,8 +1161,8 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
         return fail(h, VNECT_E_ARG, "frame slot empty or out of range");
     const unsigned long long max_in_flight = h->twins.empty() ? 2 : h->twins.size() + 1;  // one lane: two frames queue on its stream
     if (h->seq_submit - h->seq_collect >= max_in_flight) return fail(h, VNECT_E_STATE, "too many frames in flight: collect one first");
-    if (h->sharded && !h->comm)  // refuse before any filter / timestamp state changes
-        return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init before inference");
+    if (h->sharded && !comm_ready(h))  // refuse before any filter / timestamp state changes
+        return fail(h, VNECT_E_STATE, "pyramid-sharded handle: call vnect_comm_init / vnect_comm_p2p_init before inference");
     const auto& si = h->slots[slot];
     FrameParams fp;
     int rc = squarify_params(h, si.H, si.W, &fp);
@@ -1101,7 +1186,11 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
             }
     if ((rc = sync_geometry(L, fp))) return fail(h, rc, L->err);
     if (timed) HIPCK(h, hipEventRecord(h->ev[0], L->st));
-    if ((rc = run_pre(L, dyn))) return fail(h, rc, L->err);
+    {
+        RoctxRange r("vnect:gen_input_batch");
+        if ((rc = run_pre(L, dyn))) return fail(h, rc, L->err);
+    }
+    RoctxRange r_net("vnect:conv_stack+merge+argmax");
     if (L->gexec && !timed) {
         HIPCK(h, hipGraphLaunch(L->gexec, L->st));
     } else if (L->pgexec && timed) {
@@ -1110,11 +1199,18 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
         rc = run_frame_kernels(L, timed);
         if (rc) return fail(h, rc, L->err);
     }
+    if (L->sharded) {  // the one exchange of the pyramid path, then the merge + arg-max over everybody's maps
+        if (g_roctx.pop) g_roctx.pop(), g_roctx.push("vnect:exchange+merge+argmax");
+        if ((rc = exchange_maps(L, h->seq_submit))) return fail(h, rc, L->err);
+        if ((rc = run_argmax(L))) return fail(h, rc, L->err);
+    }
+    if (g_roctx.pop) g_roctx.pop(), g_roctx.push("vnect:filters+readoff");  // r_net's pop now closes this range
     if (h->seq_submit > 0 && h->last_lane && h->last_lane != L)  // the filters are a chain: frame k's state feeds frame k+1
         HIPCK(h, hipStreamWaitEvent(L->st, h->done[(h->seq_submit - 1) % RING], 0));
     if ((rc = run_joints(L, dyn, h->h_out_dev[ring]))) return fail(h, rc, L->err);  // writes the ring slot in pinned host memory
     if (timed) HIPCK(h, hipEventRecord(h->ev[3], L->st));
     HIPCK(h, hipEventRecord(h->done[ring], L->st));
+    commit_time(h, t2d, t3d);  // only now: every launch of the frame has been accepted
     h->last_lane = L;
     L->lane_seq = (long long)h->seq_submit;
     h->slots[slot].last_use = (long long)h->seq_submit;
@@ -1134,6 +1230,10 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
     if (q == hipErrorNotReady) q = hipEventSynchronize(h->done[ring]);
     HIPCK(h, q);
     h->seq_collect++;
+    if (h->h_xstatus && *h->h_xstatus) {
+        *h->h_xstatus = 0;
+        return fail(h, VNECT_E_COMM, "pyramid exchange: a peer's maps did not arrive within the bound (ranks out of step?)");
+    }
     if (j2) memcpy(j2, h->h_out[ring]->j2d, sizeof(double) * NJ * 2);
     if (j3) memcpy(j3, h->h_out[ring]->j3d, sizeof(float) * NJ * 3);
     if (h->profiling) {
@@ -1218,66 +1318,104 @@ const char* vnect_last_error(vnect_handle* h) { return h ? h->err.c_str() : g_cr
 
 int vnect_create(const vnect_config* cfg, vnect_handle** out)
 {
-    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(vnect_config))
-        return fail(nullptr, VNECT_E_ARG, "vnect_create: bad config (struct_size mismatch)");
-    if (cfg->num_scales < 1 || cfg->num_scales > VNECT_MAX_SCALES)
-        return fail(nullptr, VNECT_E_ARG, "vnect_create: num_scales out of range");
-    if (cfg->precision != VNECT_FP32 && cfg->precision != VNECT_BF16)
-        return fail(nullptr, VNECT_E_ARG, "vnect_create: precision must be VNECT_FP32 or VNECT_BF16");
-    if (cfg->lanes < 0 || cfg->lanes > RING - 1)
-        return fail(nullptr, VNECT_E_ARG, "vnect_create: lanes must be 0 .. 3");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
-        return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: no HIP device " + std::to_string(cfg->device));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || !strstr(prop.gcnArchName, "gfx950"))
-        return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: device is not gfx950 (MI355X); kernels are built for gfx950 only");
-    const bool sharded = cfg->pyramid_nranks > 1 || (cfg->pyramid_nranks == 1 && cfg->num_scales == 1);
-    if (sharded && (cfg->pyramid_nranks != cfg->num_scales || cfg->pyramid_rank < 0 || cfg->pyramid_rank >= cfg->pyramid_nranks))
-        return fail(nullptr, VNECT_E_ARG, "vnect_create: pyramid sharding needs pyramid_nranks == num_scales and 0 <= pyramid_rank < nranks");
-    vnect_handle* h = new vnect_handle();
-    h->cfg = *cfg;
-    h->S = cfg->num_scales;
-    h->Snet = sharded ? 1 : cfg->num_scales;
-    h->bf16 = cfg->precision == VNECT_BF16;
-    h->sharded = sharded;
-    h->keep_activations = cfg->keep_activations != 0;
-    if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
-    if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
-    *out = h;  // returned even on failure below so the caller can read the message, then destroy
-    HIPCK(h, hipSetDevice(cfg->device));
-    HIPCK(h, hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
-    HIPCK(h, conv_setup());
-    h->slots.resize(h->cfg.num_frame_slots);
-    int rc;
-    if ((rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
-    if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
-    if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
-    if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
-    if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
-    for (int i = 0; i < RING; i++) {
-        HIPCK(h, hipHostMalloc((void**)&h->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
-        HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocMapped | hipHostMallocCoherent));
-        HIPCK(h, hipHostGetDevicePointer((void**)&h->h_out_dev[i], h->h_out[i], 0));
-        HIPCK(h, hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming));
-    }
-    for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
-    if ((rc = dev_alloc(h, &h->d_prof, PROF_SLOTS * 128))) return rc;
-    if ((rc = dev_alloc(h, &h->d_prof_end, (size_t)PROF_WGS * 128))) return rc;
-    HIPCK(h, hipMemset(h->d_prof_end, 0, (size_t)PROF_WGS * 128 * sizeof(unsigned long long)));
-    HIPCK(h, hipHostMalloc((void**)&h->h_prof_end, (size_t)PROF_WGS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
-    HIPCK(h, hipHostMalloc((void**)&h->h_prof, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
-    HIPCK(h, hipHostMalloc((void**)&h->h_prof_init, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
-    for (int i = 0; i < PROF_SLOTS * 128; i++) h->h_prof_init[i] = (i % PROF_SLOTS) == 0 ? ~0ull : 0, h->h_prof[i] = 0;
-    if ((rc = build_scale_tables(h))) return rc;
-    if ((rc = build_up_table(h))) return rc;
-    if ((rc = reset_filters_impl(h))) return rc;
-    h->tim.struct_size = sizeof(vnect_timings);
-    return VNECT_OK;
+    if (out) *out = nullptr;  // the guard below reports on *out once the handle exists
+    return guarded(out, [&]() -> int {
+        if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(vnect_config))
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: bad config (struct_size mismatch)");
+        if (cfg->num_scales < 1 || cfg->num_scales > VNECT_MAX_SCALES)
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: num_scales out of range");
+        if (cfg->precision != VNECT_FP32 && cfg->precision != VNECT_BF16)
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: precision must be VNECT_FP32 or VNECT_BF16");
+        if (cfg->lanes < 0 || cfg->lanes > RING - 1)
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: lanes must be 0 .. 3");
+        if (cfg->exchange != VNECT_XCHG_RCCL && cfg->exchange != VNECT_XCHG_P2P)
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: exchange must be VNECT_XCHG_RCCL or VNECT_XCHG_P2P");
+        if (cfg->preprocess_only && cfg->pyramid_nranks > 0)
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: preprocess_only and pyramid sharding exclude each other");
+        roctx_load();
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
+            return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: no HIP device " + std::to_string(cfg->device));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || !strstr(prop.gcnArchName, "gfx950"))
+            return fail(nullptr, VNECT_E_NODEVICE, "vnect_create: device is not gfx950 (MI355X); kernels are built for gfx950 only");
+        const bool sharded = cfg->pyramid_nranks > 1 || (cfg->pyramid_nranks == 1 && cfg->num_scales == 1);
+        if (sharded && (cfg->pyramid_nranks != cfg->num_scales || cfg->pyramid_rank < 0 || cfg->pyramid_rank >= cfg->pyramid_nranks))
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: pyramid sharding needs pyramid_nranks == num_scales and 0 <= pyramid_rank < nranks");
+        vnect_handle* h = new vnect_handle();
+        h->cfg = *cfg;
+        h->S = cfg->num_scales;
+        h->Snet = sharded ? 1 : cfg->num_scales;
+        h->bf16 = cfg->precision == VNECT_BF16;
+        h->sharded = sharded;
+        h->keep_activations = cfg->keep_activations != 0;
+        if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
+        if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
+        *out = h;  // returned even on failure below so the caller can read the message, then destroy
+        HIPCK(h, hipSetDevice(cfg->device));
+        HIPCK(h, hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+        HIPCK(h, conv_setup());
+        h->slots.resize(h->cfg.num_frame_slots);
+        int rc;
+        if ((rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
+        if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
+        if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
+        if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
+        for (int i = 0; i < RING; i++) {
+            HIPCK(h, hipHostMalloc((void**)&h->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
+            HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCK(h, hipHostGetDevicePointer((void**)&h->h_out_dev[i], h->h_out[i], 0));
+            HIPCK(h, hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming));
+        }
+        if (sharded && cfg->exchange == VNECT_XCHG_P2P) {
+            // fine-grained device memory: peers' stores and the system-scope loads of this device bypass its L2, so a slot is
+            // never served from a line cached two frames ago
+            void* q = nullptr;
+            hipError_t e = hipExtMallocWithFlags(&q, XCHG_BYTES, hipDeviceMallocFinegrained);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                HIPCK(h, hipMalloc(&q, XCHG_BYTES));
+            }
+            h->dev_allocs.push_back(q);
+            h->xblock = (char*)q;
+            HIPCK(h, hipMemset(h->xblock, 0, XCHG_BYTES));
+            if ((rc = dev_alloc(h, &h->xtickets, 8))) return rc;
+            HIPCK(h, hipMemset(h->xtickets, 0, 8 * sizeof(unsigned)));
+            HIPCK(h, hipHostMalloc((void**)&h->h_xstatus, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+            *h->h_xstatus = 0;
+            HIPCK(h, hipHostGetDevicePointer((void**)&h->h_xstatus_dev, h->h_xstatus, 0));
+            h->xpeer[cfg->pyramid_rank] = h->xblock;
+        }
+        HIPCK(h, hipHostMalloc((void**)&h->h_filt, 128 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCK(h, hipHostGetDevicePointer((void**)&h->h_filt_dev, h->h_filt, 0));
+        for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
+        if ((rc = dev_alloc(h, &h->d_prof, PROF_SLOTS * 128))) return rc;
+        if ((rc = dev_alloc(h, &h->d_prof_end, (size_t)PROF_WGS * 128))) return rc;
+        HIPCK(h, hipMemset(h->d_prof_end, 0, (size_t)PROF_WGS * 128 * sizeof(unsigned long long)));
+        HIPCK(h, hipHostMalloc((void**)&h->h_prof_end, (size_t)PROF_WGS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCK(h, hipHostMalloc((void**)&h->h_prof, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
+        for (int i = 0; i < PROF_SLOTS * 128; i++) h->h_prof[i] = 0;
+        if ((rc = build_scale_tables(h))) return rc;
+        if ((rc = build_up_table(h))) return rc;
+        if ((rc = reset_filters_impl(h))) return rc;
+        h->tim.struct_size = sizeof(vnect_timings);
+        if (cfg->preprocess_only) {
+            // gen_input_batch alone (the reference's static method needs no session either, estimator.py:70-81): the input
+            // batch buffer and the tables made above; no weights, no launch plan, vnect_finalize is refused
+            h->pre_only = true;
+            h->t_input4 = add_tensor(h, "input", h->Snet, BOX, BOX, 3, 4);
+            Tensor& t = h->tensors[h->t_input4];
+            char* p = nullptr;
+            if ((rc = dev_alloc(h, &p, t.bytes() + 256))) return rc;
+            t.d = (float*)p;
+        }
+        return VNECT_OK;
+    });
 }
 
 void vnect_destroy(vnect_handle* h)
@@ -1298,8 +1436,11 @@ void vnect_destroy(vnect_handle* h)
     }
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
+    for (int r = 0; r < VNECT_MAX_SCALES; r++)
+        if (h->xopened[r] && h->xpeer[r]) hipIpcCloseMemHandle(h->xpeer[r]);
+    if (h->h_xstatus) hipHostFree(h->h_xstatus);
+    if (h->h_filt) hipHostFree(h->h_filt);
     if (h->h_prof) hipHostFree(h->h_prof);
-    if (h->h_prof_init) hipHostFree(h->h_prof_init);
     if (h->h_prof_end) hipHostFree(h->h_prof_end);
     for (void* p : h->dev_allocs) hipFree(p);
     if (h->st) hipStreamDestroy(h->st);
@@ -1308,284 +1449,414 @@ void vnect_destroy(vnect_handle* h)
 
 int vnect_set_weight(vnect_handle* h, const char* name, const float* data, const int64_t* shape, int ndim)
 {
-    if (!h) return VNECT_E_ARG;
-    if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(h, VNECT_E_ARG, "vnect_set_weight: bad argument");
-    if (h->finalized) return fail(h, VNECT_E_STATE, "vnect_set_weight after vnect_finalize");
-    HostArray a;
-    size_t n = 1;
-    for (int i = 0; i < ndim; i++) {
-        if (shape[i] < 1) return fail(h, VNECT_E_ARG, "vnect_set_weight: bad shape");
-        a.shape.push_back(shape[i]);
-        n *= (size_t)shape[i];
-    }
-    a.d.assign(data, data + n);
-    h->weights[name] = std::move(a);
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(h, VNECT_E_ARG, "vnect_set_weight: bad argument");
+        if (h->finalized) return fail(h, VNECT_E_STATE, "vnect_set_weight after vnect_finalize");
+        HostArray a;
+        size_t n = 1;
+        for (int i = 0; i < ndim; i++) {
+            if (shape[i] < 1) return fail(h, VNECT_E_ARG, "vnect_set_weight: bad shape");
+            a.shape.push_back(shape[i]);
+            n *= (size_t)shape[i];
+        }
+        a.d.assign(data, data + n);
+        h->weights[name] = std::move(a);
+        return VNECT_OK;
+    });
 }
 
 int vnect_finalize(vnect_handle* h)
 {
-    if (!h) return VNECT_E_ARG;
-    if (h->finalized) return fail(h, VNECT_E_STATE, "already finalized");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    int rc = finalize_impl(h);
-    if (rc) {
-        if (h->err.empty()) h->err = "finalize failed";
-        return rc;
-    }
-    rc = build_graph(h);
-    if (rc) return rc;
-    rc = build_twins(h);
-    if (rc) return rc;
-    HIPCK(h, hipStreamSynchronize(h->st));
-    h->finalized = true;
-    h->weights.clear();
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        if (h->finalized) return fail(h, VNECT_E_STATE, "already finalized");
+        if (h->pre_only) return fail(h, VNECT_E_STATE, "vnect_finalize on a preprocess_only handle");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int rc = finalize_impl(h);
+        if (rc) {
+            if (h->err.empty()) h->err = "finalize failed";
+            return rc;
+        }
+        rc = build_graph(h);
+        if (rc) return rc;
+        rc = build_twins(h);
+        if (rc) return rc;
+        HIPCK(h, hipStreamSynchronize(h->st));
+        h->finalized = true;
+        h->weights.clear();
+        return VNECT_OK;
+    });
 }
 
 int vnect_set_scales(vnect_handle* h, const double* scales, int n)
 {
-    if (!h || !scales) return VNECT_E_ARG;
-    if (n != h->S) return fail(h, VNECT_E_ARG, "vnect_set_scales: the number of scales is fixed at create time");
-    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    HIPCK(h, hipStreamSynchronize(h->st));
-    for (vnect_handle* t : h->twins) HIPCK(h, hipStreamSynchronize(t->st));
-    double old[VNECT_MAX_SCALES];
-    memcpy(old, h->cfg.scales, sizeof old);
-    for (int i = 0; i < n; i++) h->cfg.scales[i] = scales[i];
-    int rc = build_scale_tables(h);
-    if (rc) {
-        memcpy(h->cfg.scales, old, sizeof old);
-        build_scale_tables(h);
-    }
-    return rc;
+    return guarded(&h, [&]() -> int {
+        if (!h || !scales) return VNECT_E_ARG;
+        if (n != h->S) return fail(h, VNECT_E_ARG, "vnect_set_scales: the number of scales is fixed at create time");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        HIPCK(h, hipStreamSynchronize(h->st));
+        for (vnect_handle* t : h->twins) HIPCK(h, hipStreamSynchronize(t->st));
+        double old[VNECT_MAX_SCALES];
+        memcpy(old, h->cfg.scales, sizeof old);
+        for (int i = 0; i < n; i++) h->cfg.scales[i] = scales[i];
+        int rc = build_scale_tables(h);
+        if (rc) {
+            memcpy(h->cfg.scales, old, sizeof old);
+            build_scale_tables(h);
+        }
+        return rc;
+    });
 }
 
 int vnect_forward(vnect_handle* h, const float* batch, int num_images, float* out)
 {
-    if (!h || !batch || !out) return VNECT_E_ARG;
-    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_forward before vnect_finalize");
-    if (num_images != h->Snet)
-        return fail(h, VNECT_E_ARG, "vnect_forward: num_images must equal num_scales (1 on a pyramid-sharded handle)");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    const long long npix = (long long)h->Snet * BOX * BOX;
-    HIPCK(h, hipMemcpyAsync(h->in3, batch, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->st));
-    HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->bf16, h->st));
-    int rc = run_network(h, false);
-    if (rc) return rc;
-    const Tensor& t = h->tensors[h->t_out];
-    HIPCK(h, hipMemcpyAsync(out, t.d, t.bytes(), hipMemcpyDeviceToHost, h->st));
-    HIPCK(h, hipStreamSynchronize(h->st));
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !batch || !out) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_forward before vnect_finalize");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        if (num_images != h->Snet)
+            return fail(h, VNECT_E_ARG, "vnect_forward: num_images must equal num_scales (1 on a pyramid-sharded handle)");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        const long long npix = (long long)h->Snet * BOX * BOX;
+        HIPCK(h, hipMemcpyAsync(h->in3, batch, npix * 3 * sizeof(float), hipMemcpyHostToDevice, h->st));
+        HIPCK(h, launch_pad3to4(h->in3, h->tensors[h->t_input4].d, npix, h->bf16, h->st));
+        int rc = run_network(h, false);
+        if (rc) return rc;
+        const Tensor& t = h->tensors[h->t_out];
+        HIPCK(h, hipMemcpyAsync(out, t.d, t.bytes(), hipMemcpyDeviceToHost, h->st));
+        HIPCK(h, hipStreamSynchronize(h->st));
+        return VNECT_OK;
+    });
 }
 
 int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, float* batch_out,
                      double* scaler, int32_t* offset_x, int32_t* offset_y)
 {
-    if (!h || !bgr) return VNECT_E_ARG;
-    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_preprocess before vnect_finalize");
-    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
-    if (rc) return rc;
-    FrameParams fp;
-    if ((rc = squarify_params(h, H, W, &fp))) return rc;
-    FrameDyn dyn{};
-    dyn.row_stride = h->slots[0].stride, dyn.frame = h->frames;
-    if ((rc = sync_geometry(h, fp))) return rc;
-    if ((rc = run_pre(h, dyn))) return rc;
-    if (batch_out) {
-        const long long npix = (long long)h->Snet * BOX * BOX;
-        HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->bf16, h->st));
-        HIPCK(h, hipMemcpyAsync(batch_out, h->in3, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->st));
-    }
-    HIPCK(h, hipStreamSynchronize(h->st));
-    if (scaler) *scaler = fp.scaler;
-    if (offset_x) *offset_x = fp.offx;
-    if (offset_y) *offset_y = fp.offy;
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !bgr) return VNECT_E_ARG;
+        if (!h->finalized && !h->pre_only) return fail(h, VNECT_E_STATE, "vnect_preprocess before vnect_finalize");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
+        if (rc) return rc;
+        FrameParams fp;
+        if ((rc = squarify_params(h, H, W, &fp))) return rc;
+        FrameDyn dyn{};
+        dyn.row_stride = h->slots[0].stride, dyn.frame = h->frames;
+        if ((rc = sync_geometry(h, fp))) return rc;
+        if ((rc = run_pre(h, dyn))) return rc;
+        if (batch_out) {
+            const long long npix = (long long)h->Snet * BOX * BOX;
+            HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->bf16, h->st));
+            HIPCK(h, hipMemcpyAsync(batch_out, h->in3, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+        }
+        HIPCK(h, hipStreamSynchronize(h->st));
+        if (scaler) *scaler = fp.scaler;
+        if (offset_x) *offset_x = fp.offx;
+        if (offset_y) *offset_y = fp.offy;
+        return VNECT_OK;
+    });
 }
 
 int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d, double scaler, int32_t offset_x,
                       int32_t offset_y, double* j2, float* j3)
 {
-    if (!h || !maps || !j2 || !j3) return VNECT_E_ARG;
-    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_postprocess before vnect_finalize");
-    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
-    if (!(scaler > 0)) return fail(h, VNECT_E_ARG, "scaler must be positive");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    int rc = check_time(h, t2d, t3d);
-    if (rc) return rc;
-    float* dst = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, hipMemcpyAsync(dst, maps, (size_t)h->S * HM * HM * MAPC * sizeof(float), hipMemcpyHostToDevice, h->st));
-    FrameParams fp;
-    memset(&fp, 0, sizeof fp);
-    fp.scaler = scaler, fp.offx = offset_x, fp.offy = offset_y;
-    FrameDyn dyn{};
-    dyn.t2d = t2d, dyn.t3d = t3d;
-    if ((rc = sync_geometry(h, fp))) return rc;
-    if ((rc = run_argmax(h))) return rc;
-    if ((rc = run_joints(h, dyn, h->h_out_dev[0]))) return rc;
-    HIPCK(h, hipStreamSynchronize(h->st));
-    memcpy(j2, h->h_out[0]->j2d, sizeof(double) * NJ * 2);
-    memcpy(j3, h->h_out[0]->j3d, sizeof(float) * NJ * 3);
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !maps || !j2 || !j3) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_postprocess before vnect_finalize");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        if (!(scaler > 0)) return fail(h, VNECT_E_ARG, "scaler must be positive");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int rc = check_time(h, t2d, t3d);
+        if (rc) return rc;
+        float* dst = h->sharded ? h->gather : h->tensors[h->t_out].d;
+        HIPCK(h, hipMemcpyAsync(dst, maps, (size_t)h->S * HM * HM * MAPC * sizeof(float), hipMemcpyHostToDevice, h->st));
+        FrameParams fp;
+        memset(&fp, 0, sizeof fp);
+        fp.scaler = scaler, fp.offx = offset_x, fp.offy = offset_y;
+        FrameDyn dyn{};
+        dyn.t2d = t2d, dyn.t3d = t3d;
+        if ((rc = sync_geometry(h, fp))) return rc;
+        if ((rc = run_argmax(h))) return rc;
+        if ((rc = run_joints(h, dyn, h->h_out_dev[0]))) return rc;
+        commit_time(h, t2d, t3d);
+        HIPCK(h, hipStreamSynchronize(h->st));
+        memcpy(j2, h->h_out[0]->j2d, sizeof(double) * NJ * 2);
+        memcpy(j3, h->h_out[0]->j3d, sizeof(float) * NJ * 3);
+        return VNECT_OK;
+    });
 }
 
 int vnect_upload_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
 {
-    if (!h) return VNECT_E_ARG;
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    return upload_frame_impl(h, slot, bgr, H, W, row_stride);
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        return upload_frame_impl(h, slot, bgr, H, W, row_stride);
+    });
 }
 
 int vnect_submit_resident(vnect_handle* h, int slot, double t2d, double t3d)
 {
-    if (!h) return VNECT_E_ARG;
-    if (!h->finalized) return fail(h, VNECT_E_STATE, "inference before vnect_finalize");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    int ring;
-    return enqueue_frame(h, slot, t2d, t3d, &ring);
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "inference before vnect_finalize");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int ring;
+        return enqueue_frame(h, slot, t2d, t3d, &ring);
+    });
 }
 
 int vnect_collect(vnect_handle* h, double* j2, float* j3)
 {
-    if (!h) return VNECT_E_ARG;
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    return collect_impl(h, j2, j3);
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        return collect_impl(h, j2, j3);
+    });
 }
 
 int vnect_infer_resident(vnect_handle* h, int slot, double t2d, double t3d, double* j2, float* j3)
 {
-    if (!h || !j2 || !j3) return VNECT_E_ARG;
-    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
-    int rc = vnect_submit_resident(h, slot, t2d, t3d);
-    if (rc) return rc;
-    return collect_impl(h, j2, j3);
+    return guarded(&h, [&]() -> int {
+        if (!h || !j2 || !j3) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "inference before vnect_finalize");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        int rc = vnect_submit_resident(h, slot, t2d, t3d);
+        if (rc) return rc;
+        return collect_impl(h, j2, j3);
+    });
 }
 
 int vnect_infer(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, double t2d, double t3d,
                 double* j2, float* j3)
 {
-    if (!h || !bgr || !j2 || !j3) return VNECT_E_ARG;
-    if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_infer before vnect_finalize");
-    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
-    if (rc) return rc;
-    return vnect_infer_resident(h, 0, t2d, t3d, j2, j3);
+    return guarded(&h, [&]() -> int {
+        if (!h || !bgr || !j2 || !j3) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_infer before vnect_finalize");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
+        if (rc) return rc;
+        return vnect_infer_resident(h, 0, t2d, t3d, j2, j3);
+    });
+}
+
+int vnect_joint_filter(vnect_handle* h, int dim, const double* joints_in, int values_are_f32, double t, double* joints_out)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h || !joints_in || !joints_out || (dim != 2 && dim != 3)) return h ? fail(h, VNECT_E_ARG, "vnect_joint_filter: bad argument") : VNECT_E_ARG;
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        // the timestamp rules of check_time, for the one bank this call advances
+        const bool have = dim == 2 ? h->have2 : h->have3;
+        const double last = dim == 2 ? h->last2 : h->last3;
+        if (have && last != 0.0 && t != 0.0) {
+            if (t == last) return fail(h, VNECT_E_TIMESTAMP, "timestamp equals the previous one of this filter bank");
+            if (t < last) return fail(h, VNECT_E_TIMEORDER, "timestamp is earlier than the previous one of this filter bank");
+        }
+        const int n = NJ * dim;
+        memcpy(h->h_filt, joints_in, sizeof(double) * n);
+        HIPCK(h, launch_filter(h->d_fb, dim, values_are_f32 != 0, h->cfg.numpy_promotion, t, h->h_filt_dev, h->h_filt_dev + 64, h->st));
+        HIPCK(h, hipStreamSynchronize(h->st));
+        if (dim == 2) h->have2 = true, h->last2 = t;
+        else h->have3 = true, h->last3 = t;
+        memcpy(joints_out, h->h_filt + 64, sizeof(double) * n);
+        return VNECT_OK;
+    });
 }
 
 int vnect_reset_filters(vnect_handle* h)
 {
-    if (!h) return VNECT_E_ARG;
-    if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    return reset_filters_impl(h);
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        return reset_filters_impl(h);
+    });
 }
 
 int vnect_read_activation(vnect_handle* h, const char* name, float* out, int64_t capacity, int32_t* shape4)
 {
-    if (!h || !name || !shape4) return VNECT_E_ARG;
-    if (!h->finalized) return fail(h, VNECT_E_STATE, "not finalized");
-    auto it = h->tensor_by_name.find(name);
-    if (it == h->tensor_by_name.end()) return fail(h, VNECT_E_ARG, std::string("no activation named ") + name);
-    const Tensor& t = h->tensors[it->second];
-    shape4[0] = t.S, shape4[1] = t.H, shape4[2] = t.W, shape4[3] = t.C;
-    if (!out) return VNECT_OK;
-    if (!h->keep_activations && it->second != h->t_out)
-        return fail(h, VNECT_E_STATE, "vnect_read_activation: inner layers share an arena; create the handle with keep_activations = 1");
-    const size_t npix = (size_t)t.S * t.H * t.W;
-    if ((int64_t)(npix * t.C) > capacity) return fail(h, VNECT_E_ARG, "vnect_read_activation: capacity too small");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    HIPCK(h, hipStreamSynchronize(h->st));
-    if (t.esz == 4) {
-        HIPCK(h, hipMemcpy2D(out, (size_t)t.C * sizeof(float), t.d, (size_t)t.Cs * sizeof(float), (size_t)t.C * sizeof(float),
-                             npix, hipMemcpyDeviceToHost));
-    } else {  // bf16 activations: fetch raw, widen on the host
-        std::vector<uint16_t> raw(npix * t.C);
-        HIPCK(h, hipMemcpy2D(raw.data(), (size_t)t.C * 2, t.d, (size_t)t.Cs * 2, (size_t)t.C * 2, npix, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < raw.size(); i++) out[i] = from_bf16(raw[i]);
-    }
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !name || !shape4) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "not finalized");
+        auto it = h->tensor_by_name.find(name);
+        if (it == h->tensor_by_name.end()) return fail(h, VNECT_E_ARG, std::string("no activation named ") + name);
+        const Tensor& t = h->tensors[it->second];
+        shape4[0] = t.S, shape4[1] = t.H, shape4[2] = t.W, shape4[3] = t.C;
+        if (!out) return VNECT_OK;
+        if (!h->keep_activations && it->second != h->t_out)
+            return fail(h, VNECT_E_STATE, "vnect_read_activation: inner layers share an arena; create the handle with keep_activations = 1");
+        const size_t npix = (size_t)t.S * t.H * t.W;
+        if ((int64_t)(npix * t.C) > capacity) return fail(h, VNECT_E_ARG, "vnect_read_activation: capacity too small");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        HIPCK(h, hipStreamSynchronize(h->st));
+        if (t.esz == 4) {
+            HIPCK(h, hipMemcpy2D(out, (size_t)t.C * sizeof(float), t.d, (size_t)t.Cs * sizeof(float), (size_t)t.C * sizeof(float),
+                                 npix, hipMemcpyDeviceToHost));
+        } else {  // bf16 activations: fetch raw, widen on the host
+            std::vector<uint16_t> raw(npix * t.C);
+            HIPCK(h, hipMemcpy2D(raw.data(), (size_t)t.C * 2, t.d, (size_t)t.Cs * 2, (size_t)t.C * 2, npix, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < raw.size(); i++) out[i] = from_bf16(raw[i]);
+        }
+        return VNECT_OK;
+    });
 }
 
 int vnect_get_layer_stamps(vnect_handle* h, int idx, uint64_t* out24)
 {
-    if (!h || !out24 || idx < 0 || idx >= (int)h->layers.size()) return h ? fail(h, VNECT_E_ARG, "bad layer index") : VNECT_E_ARG;
-    for (int k = 0; k < PROF_SLOTS; k++) out24[k] = h->h_prof[PROF_SLOTS * idx + k];
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !out24 || idx < 0 || idx >= (int)h->layers.size()) return h ? fail(h, VNECT_E_ARG, "bad layer index") : VNECT_E_ARG;
+        for (int k = 0; k < PROF_SLOTS; k++) out24[k] = h->h_prof[PROF_SLOTS * idx + k];
+        return VNECT_OK;
+    });
 }
 
 int vnect_set_profiling(vnect_handle* h, int on)
 {
-    if (!h) return VNECT_E_ARG;
-    h->profiling = on != 0;
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        h->profiling = on != 0;
+        return VNECT_OK;
+    });
 }
 
 int vnect_get_timings(vnect_handle* h, vnect_timings* out)
 {
-    if (!h || !out || out->struct_size != (int32_t)sizeof(vnect_timings)) return VNECT_E_ARG;
-    *out = h->tim;
-    out->struct_size = sizeof(vnect_timings);
-    out->conv_launches = h->conv_launches;
-    out->conv_flops = h->conv_flops;
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !out || out->struct_size != (int32_t)sizeof(vnect_timings)) return VNECT_E_ARG;
+        *out = h->tim;
+        out->struct_size = sizeof(vnect_timings);
+        out->conv_launches = h->conv_launches;
+        out->conv_flops = h->conv_flops;
+        return VNECT_OK;
+    });
 }
 
 int vnect_reset_timings(vnect_handle* h)
 {
-    if (!h) return VNECT_E_ARG;
-    memset(&h->tim, 0, sizeof h->tim);
-    h->tim.struct_size = sizeof(vnect_timings);
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        memset(&h->tim, 0, sizeof h->tim);
+        h->tim.struct_size = sizeof(vnect_timings);
+        return VNECT_OK;
+    });
 }
 
 int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out)
 {
-    if (!h || !out || idx < 0 || idx >= (int)h->layers.size()) return VNECT_E_ARG;
-    const Layer& L = h->layers[idx];
-    memset(out, 0, sizeof *out);
-    snprintf(out->name, sizeof out->name, "%s", L.name.c_str());
-    if (L.op == OP_CONV) {
-        out->M = L.a.M * L.a.nphase, out->N = L.Nreal, out->K = L.Kreal;
-        out->tile_m = L.BM, out->tile_n = L.BN, out->split_k = L.a.ksplit;
-        out->workgroups = ((L.a.M + L.BM - 1) / L.BM) * (L.a.Npad / L.BN) * L.a.nphase * L.a.ksplit;
-        out->flops = L.flops;
-    }
-    out->last_ms = L.last_ms;
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !out || idx < 0 || idx >= (int)h->layers.size()) return VNECT_E_ARG;
+        const Layer& L = h->layers[idx];
+        memset(out, 0, sizeof *out);
+        snprintf(out->name, sizeof out->name, "%s", L.name.c_str());
+        if (L.op == OP_CONV) {
+            out->M = L.a.M * L.a.nphase, out->N = L.Nreal, out->K = L.Kreal;
+            out->tile_m = L.BM, out->tile_n = L.BN, out->split_k = L.a.ksplit;
+            out->workgroups = ((L.a.M + L.BM - 1) / L.BM) * (L.a.Npad / L.BN) * L.a.nphase * L.a.ksplit;
+            out->flops = L.flops;
+        }
+        out->last_ms = L.last_ms;
+        return VNECT_OK;
+    });
 }
 
 int vnect_comm_unique_id(void* id128)
 {
-    if (!id128) return VNECT_E_ARG;
-    if (!load_rccl()) return fail(nullptr, VNECT_E_COMM, "librccl.so not available");
-    nccl_uid u;
-    if (p_ncclGetUniqueId(&u) != 0) return fail(nullptr, VNECT_E_COMM, "ncclGetUniqueId failed");
-    memcpy(id128, &u, sizeof u);
-    return VNECT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!id128) return VNECT_E_ARG;
+        if (!load_rccl()) return fail(nullptr, VNECT_E_COMM, "librccl.so not available");
+        nccl_uid u;
+        if (p_ncclGetUniqueId(&u) != 0) return fail(nullptr, VNECT_E_COMM, "ncclGetUniqueId failed");
+        memcpy(id128, &u, sizeof u);
+        return VNECT_OK;
+    });
 }
 
 int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128)
 {
-    if (!h || !id128) return VNECT_E_ARG;
-    if (!h->sharded) return fail(h, VNECT_E_STATE, "vnect_comm_init: handle was not created with pyramid_nranks");
-    if (h->comm) return fail(h, VNECT_E_STATE, "vnect_comm_init: communicator already initialised");
-    if (nranks != h->cfg.pyramid_nranks || rank != h->cfg.pyramid_rank)
-        return fail(h, VNECT_E_ARG, "vnect_comm_init: rank / nranks differ from the handle's pyramid configuration");
-    if (!load_rccl()) return fail(h, VNECT_E_COMM, "librccl.so not available");
-    HIPCK(h, hipSetDevice(h->cfg.device));
-    nccl_uid u;
-    memcpy(&u, id128, sizeof u);
-    const int rc = p_ncclCommInitRank(&h->comm, nranks, u, rank);
-    if (rc != 0) {
-        h->comm = nullptr;
-        return fail(h, VNECT_E_COMM, std::string("ncclCommInitRank: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"));
-    }
-    return VNECT_OK;
+    return guarded(&h, [&]() -> int {
+        if (!h || !id128) return VNECT_E_ARG;
+        if (!h->sharded) return fail(h, VNECT_E_STATE, "vnect_comm_init: handle was not created with pyramid_nranks");
+        if (h->comm) return fail(h, VNECT_E_STATE, "vnect_comm_init: communicator already initialised");
+        if (nranks != h->cfg.pyramid_nranks || rank != h->cfg.pyramid_rank)
+            return fail(h, VNECT_E_ARG, "vnect_comm_init: rank / nranks differ from the handle's pyramid configuration");
+        if (!load_rccl()) return fail(h, VNECT_E_COMM, "librccl.so not available");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        nccl_uid u;
+        memcpy(&u, id128, sizeof u);
+        const int rc = p_ncclCommInitRank(&h->comm, nranks, u, rank);
+        if (rc != 0) {
+            h->comm = nullptr;
+            return fail(h, VNECT_E_COMM, std::string("ncclCommInitRank: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"));
+        }
+        return VNECT_OK;
+    });
+}
+
+/* blob layout (128 bytes): [0,64) hipIpcMemHandle_t of the exchange block, [64,72) its address in the exporting process,
+ * [72,80) that process's pid, [80,84) its device ordinal */
+int vnect_comm_p2p_export(vnect_handle* h, void* blob128)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h || !blob128) return VNECT_E_ARG;
+        if (!h->sharded || h->cfg.exchange != VNECT_XCHG_P2P) return fail(h, VNECT_E_STATE, "vnect_comm_p2p_export: handle was not created with exchange = VNECT_XCHG_P2P");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        char* b = (char*)blob128;
+        memset(b, 0, 128);
+        hipIpcMemHandle_t ipc;
+        static_assert(sizeof(ipc) <= 64, "blob layout");
+        hipError_t e = hipIpcGetMemHandle(&ipc, h->xblock);
+        if (e == hipSuccess) memcpy(b, &ipc, sizeof ipc);
+        else (void)hipGetLastError();  // still usable inside this process (the raw address below)
+        const unsigned long long addr = (unsigned long long)(uintptr_t)h->xblock, pid = (unsigned long long)getpid();
+        const int dev = h->cfg.device, has_ipc = e == hipSuccess;
+        memcpy(b + 64, &addr, 8), memcpy(b + 72, &pid, 8), memcpy(b + 80, &dev, 4), memcpy(b + 84, &has_ipc, 4);
+        return VNECT_OK;
+    });
+}
+
+int vnect_comm_p2p_init(vnect_handle* h, int rank, int nranks, const void* blobs)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h || !blobs) return VNECT_E_ARG;
+        if (!h->sharded || h->cfg.exchange != VNECT_XCHG_P2P) return fail(h, VNECT_E_STATE, "vnect_comm_p2p_init: handle was not created with exchange = VNECT_XCHG_P2P");
+        if (h->p2p_ready) return fail(h, VNECT_E_STATE, "vnect_comm_p2p_init: peers already connected");
+        if (nranks != h->cfg.pyramid_nranks || rank != h->cfg.pyramid_rank)
+            return fail(h, VNECT_E_ARG, "vnect_comm_p2p_init: rank / nranks differ from the handle's pyramid configuration");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        for (int r = 0; r < nranks; r++) {
+            if (r == rank) continue;
+            const char* b = (const char*)blobs + (size_t)r * 128;
+            unsigned long long addr, pid;
+            int dev, has_ipc;
+            memcpy(&addr, b + 64, 8), memcpy(&pid, b + 72, 8), memcpy(&dev, b + 80, 4), memcpy(&has_ipc, b + 84, 4);
+            if (pid == (unsigned long long)getpid()) {
+                // a peer handle of this very process (several GPUs driven by one process, or the one-GPU test): its address is
+                // valid here; make the other device reachable
+                if (dev != h->cfg.device) {
+                    hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                        return fail(h, VNECT_E_COMM, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                    (void)hipGetLastError();
+                }
+                h->xpeer[r] = (char*)(uintptr_t)addr;
+            } else {
+                if (!has_ipc) return fail(h, VNECT_E_COMM, "vnect_comm_p2p_init: peer could not export its exchange block (hipIpcGetMemHandle failed there)");
+                hipIpcMemHandle_t ipc;
+                memcpy(&ipc, b, sizeof ipc);
+                void* q = nullptr;
+                hipError_t e = hipIpcOpenMemHandle(&q, ipc, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) return fail(h, VNECT_E_COMM, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+                h->xpeer[r] = (char*)q, h->xopened[r] = true;
+            }
+        }
+        h->p2p_ready = true;
+        return VNECT_OK;
+    });
 }
 
 }  // extern "C"

@@ -82,10 +82,8 @@ class VNectEstimator:
         h = _handle
         own = h is None or h.num_scales != len(scales)
         if own:
-            h = _native.Handle(list(scales))
-            # pre-processing needs no weights, but the handle must be planned
-            h.set_weights(synthetic_weights())
-            h.finalize()
+            # a pre-processing-only handle: resize tables + the batch buffer, no weights, no launch plan
+            h = _native.Handle(list(scales), preprocess_only=True)
         else:
             h.set_scales(scales)
         try:
@@ -94,13 +92,38 @@ class VNectEstimator:
             if own:
                 h.close()
 
-    def joint_filter(self, joints, dim=2):
-        raise NotImplementedError("the OneEuro filters run inside the fused device kernel (see vnect_postprocess); "
-                                  "use VNectEstimator.postprocess(maps, ...) for the filtered joints")
+    def joint_filter(self, joints, dim=2, timestamp=None):
+        """src/estimator.py:83-95: the estimator's 2-D (``dim=2``) or 3-D OneEuro bank applied to ``joints`` IN PLACE; returns
+        ``joints``.  The filter state lives on the device (the same banks ``__call__`` advances), so this runs one tiny
+        kernel.  A float32 array is filtered the way the reference filters its float32 ``joints_3d`` (numpy scalar promotion,
+        ``numpy_promotion=``), any other dtype in float64 like ``joints_2d``.  ``timestamp=`` is additive (default: one
+        ``time.time()`` per call, like the reference)."""
+        t = time.time() if timestamp is None else float(timestamp)
+        a = joints if isinstance(joints, np.ndarray) else np.asarray(joints)
+        if a.ndim != 2 or a.shape[0] < self.joints_sum or a.shape[1] < dim:
+            raise IndexError("joints must hold at least (%d, %d) values" % (self.joints_sum, dim))
+        dim = 2 if dim == 2 else 3  # the reference's `else` branch takes every other value as 3
+        try:
+            out = self._h.joint_filter(dim, a[:self.joints_sum, :dim], a.dtype == np.float32, t)
+        except _native.VnectError as e:
+            self._raise_like_reference(e)
+        a[:self.joints_sum, :dim] = out  # in place; numpy casts to the array's dtype as `joints[i, 0] = ...` does
+        return joints
+
+    @staticmethod
+    def _raise_like_reference(e):
+        if e.code == _native.E_TIMESTAMP:
+            raise ZeroDivisionError("float division by zero") from e  # src/OneEuroFilter.py:66
+        if e.code == _native.E_TIMEORDER:  # negative freq -> alpha outside (0, 1]: LowPassFilter.__setAlpha, OneEuroFilter.py:19-23
+            raise ValueError("alpha should be in (0.0, 1.0]: timestamp earlier than the previous one") from e
+        raise e
 
     def postprocess(self, maps, timestamp=None, scaler=1.0, offset_x=0, offset_y=0):
         t2d, t3d = self._stamps(timestamp)
-        return self._h.postprocess(maps, t2d, t3d, scaler, offset_x, offset_y)
+        try:
+            return self._h.postprocess(maps, t2d, t3d, scaler, offset_x, offset_y)
+        except _native.VnectError as e:
+            self._raise_like_reference(e)
 
     def forward(self, batch):
         """sess.run equivalent (src/estimator.py:100-104): (S,368,368,3) -> (S,46,46,84)."""
@@ -120,9 +143,7 @@ class VNectEstimator:
         try:
             joints_2d, joints_3d = self._h.infer(img_input, t2d, t3d)
         except _native.VnectError as e:
-            if e.code == _native.E_TIMESTAMP:
-                raise ZeroDivisionError("float division by zero") from e  # src/OneEuroFilter.py:66
-            raise
+            self._raise_like_reference(e)
         if self.verbose:
             print('FPS: {:>2.2f}'.format(1 / max(time.time() - t0, 1e-9)))
         return joints_2d, joints_3d
@@ -138,9 +159,7 @@ class VNectEstimator:
             self._h.upload_frame(slot, img_input)
             self._h.submit_resident(slot, t2d, t3d)
         except _native.VnectError as e:
-            if e.code == _native.E_TIMESTAMP:
-                raise ZeroDivisionError("float division by zero") from e
-            raise
+            self._raise_like_reference(e)
         self._submitted += 1
 
     def collect(self):

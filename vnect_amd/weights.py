@@ -170,7 +170,12 @@ def check_schema(weights):
 
 
 def load_weights(path):
-    """Read a reference ``params.pkl`` (caffe2pkl.py output) or an ``.npz`` with the same keys."""
+    """Read a reference ``params.pkl`` (caffe2pkl.py:83-88 output) or an ``.npz`` with the same keys.
+
+    Prefer ``.npz`` (``np.savez(path, **weights)``): it is plain arrays.  A pickle is what the reference ships between its
+    tools (``vnect_model.py:219-222`` unpickles it the same way), but ``pickle.load`` runs arbitrary code from the file: only
+    load pickles you made yourself.  Raises ``ValueError`` when an array of the schema is missing or mis-shaped.
+    """
     if str(path).endswith(".npz"):
         with np.load(path) as z:
             w = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
