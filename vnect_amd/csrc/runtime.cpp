@@ -542,27 +542,29 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     return L.out;
 }
 
-// Two 1x1 convs of one input with one stride (branch2a with ReLU, branch1 without; vnect_model.py:32-35,64-67,
-// 106-109,168-175) as ONE launch: weights concatenated along N ([branch2a | branch1]), ReLU on the first block of
-// columns only, two output tensors.  Returns the branch2a tensor, *shortcut gets the branch1 tensor.
+// Two convs of ONE input with one kernel size and stride as ONE launch: weights concatenated along N ([a | b]), two output
+// tensors, ReLU per column block.  Used for (i) branch2a (ReLU) + branch1 (none), the two 1x1 convs at the head of a projection
+// block (vnect_model.py:32-35,64-67,106-109,168-175), and (ii) res2b_branch2b + res2c_branch2b, two 3x3 convs that both read
+// res2b_branch2a in the reference's wiring (vnect_model.py:50,56).  Returns the first tensor, *second gets the other one.
 int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std::string& sb, int cout_b, int in,
-                  int stride, int* shortcut)
+                  int stride, int* second, int k = 1, bool relu_b = false)
 {
     const Tensor tin = h->tensors[in];
     const int cin = tin.C;
-    const HostArray* Wa = get_w(h, sa + "/weights", {1, 1, cin, cout_a});
+    const HostArray* Wa = get_w(h, sa + "/weights", {k, k, cin, cout_a});
     const HostArray* Ba = Wa ? get_w(h, sa + "/biases", {cout_a}) : nullptr;
-    const HostArray* Wb = Ba ? get_w(h, sb + "/weights", {1, 1, cin, cout_b}) : nullptr;
+    const HostArray* Wb = Ba ? get_w(h, sb + "/weights", {k, k, cin, cout_b}) : nullptr;
     const HostArray* Bb = Wb ? get_w(h, sb + "/biases", {cout_b}) : nullptr;
     if (!Bb) return -1;
     const int EPR = h->bf16 ? 64 : 32;
-    if (cout_a % 64 || tin.Cs % EPR) {
-        h->err = "internal: paired conv needs 64-aligned split";
+    if (cout_a % 64 || tin.Cs % EPR || (k != 1 && (k != 3 || stride != 1))) {
+        h->err = "internal: paired conv needs a 64-aligned split, whole K chunks and 1x1 or 3x3 stride 1";
         return -1;
     }
-    const int ho = (tin.H - 1) / stride + 1, wo = (tin.W - 1) / stride + 1;
+    int ho = (tin.H - 1) / stride + 1, wo = (tin.W - 1) / stride + 1, pt = 0, pl = 0;  // 1x1: VALID
+    if (k == 3) same_pad(tin.H, 3, 1, &ho, &pt), same_pad(tin.W, 3, 1, &wo, &pl);
     Layer L;
-    L.op = OP_CONV, L.name = sa + "+" + sb.substr(sb.find('_') + 1), L.in = in;
+    L.op = OP_CONV, L.name = sa + "+" + (k == 1 ? sb.substr(sb.find('_') + 1) : sb), L.in = in;
     L.out = add_tensor(h, sa, tin.S, ho, wo, cout_a, cout_a);
     L.out2 = add_tensor(h, sb, tin.S, ho, wo, cout_b, cout_b);
     ConvArgs& a = L.a;
@@ -570,25 +572,29 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     a.Ho = ho, a.Wo = wo, a.M = tin.S * ho * wo, a.stride = stride;
     a.OH = ho, a.OW = wo, a.os = 1, a.nphase = 1;
     a.ldc = cout_a, a.ldc2 = cout_b, a.split_n = cout_a, a.ldr = 0;
-    a.relu_cols = cout_a;
-    a.ntaps = 1, a.cpt = tin.Cs / EPR, a.K = tin.Cs;
+    a.relu_cols = relu_b ? cout_a + cout_b : cout_a;
+    a.ntaps = k * k, a.cpt = tin.Cs / EPR, a.K = k * k * tin.Cs;
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++) L.dy[ky * k + kx] = ky - pt, L.dx[ky * k + kx] = kx - pl;
     a.bf16 = h->bf16;
-    L.Nreal = cout_a + cout_b, L.Kreal = cin;
+    L.Nreal = cout_a + cout_b, L.Kreal = k * k * cin;
     a.Nvalid = L.Nreal;
-    L.flops = 2.0 * a.M * (double)cin * L.Nreal;
+    L.flops = 2.0 * a.M * (double)L.Kreal * L.Nreal;
     choose_tile(L, (long long)a.M);
     if (L.BN != 64 || L.a.ksplit != 1 || L.KG != 1) L.BM = 64, L.BN = 64, L.KG = 1, L.a.ksplit = 1;  // the column split relies on 64-wide tiles, no slabs
     a.Npad = round_up(L.Nreal, 64);
     std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
-    for (int ci = 0; ci < cin; ci++) {
-        for (int n = 0; n < cout_a; n++) wp[(size_t)n * a.K + ci] = Wa->d[(size_t)ci * cout_a + n];
-        for (int n = 0; n < cout_b; n++) wp[(size_t)(cout_a + n) * a.K + ci] = Wb->d[(size_t)ci * cout_b + n];
-    }
+    for (int t = 0; t < k * k; t++)
+        for (int ci = 0; ci < cin; ci++) {
+            const size_t kidx = (size_t)t * tin.Cs + ci;
+            for (int n = 0; n < cout_a; n++) wp[(size_t)n * a.K + kidx] = Wa->d[((size_t)t * cin + ci) * cout_a + n];
+            for (int n = 0; n < cout_b; n++) wp[(size_t)(cout_a + n) * a.K + kidx] = Wb->d[((size_t)t * cin + ci) * cout_b + n];
+        }
     for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
     for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
     if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
     h->layers.push_back(L);
-    *shortcut = L.out2;
+    *second = L.out2;
     return L.out;
 }
 
@@ -647,21 +653,24 @@ int finalize_impl(vnect_handle* h)
     };
     int r = proj("res2a", pool1, 64, 256, 1);
     NEED(r);
-    int r2b_2a = -1;
-    int r2b = ident("res2b", r, 64, 256, &r2b_2a);
-    NEED(r2b);
-    {
-        // vnect_model.py:54-57: res2c_branch2b consumes res2b_branch2a; res2c_branch2a is dead and pruned
-        int a = r2b_2a;
-        if (h->cfg.paper_res2c) {
-            a = conv("res2c_branch2a", r2b, 1, 1, 64, true);
-            NEED(a);
-        } else if (!get_w(h, "res2c_branch2a/weights", {1, 1, 256, 64})) {
-            return VNECT_E_ARG;  // schema completeness, like the reference's load_weights
-        }
-        int b = conv("res2c_branch2b", a, 3, 1, 64, true);
-        NEED(b);
-        r = conv("res2c_branch2c", b, 1, 1, 256, true, r2b, "res2c");
+    if (h->cfg.paper_res2c) {
+        r = ident("res2b", r, 64, 256);
+        NEED(r);
+        r = ident("res2c", r, 64, 256);
+        NEED(r);
+    } else {
+        // vnect_model.py:50-57: res2c_branch2b consumes res2b_branch2a (`:56`), res2c_branch2a is dead and pruned -- so the two
+        // 3x3 convs res2b_branch2b and res2c_branch2b read the SAME tensor and run as one dual-output launch
+        if (!get_w(h, "res2c_branch2a/weights", {1, 1, 256, 64})) return VNECT_E_ARG;  // schema completeness, like the reference's load_weights
+        const int x = r;
+        int a = conv("res2b_branch2a", x, 1, 1, 64, true);
+        NEED(a);
+        int b2 = -1;
+        int b1 = add_conv_pair(h, "res2b_branch2b", 64, "res2c_branch2b", 64, a, 1, &b2, 3, true);
+        NEED(b1);
+        int r2b = conv("res2b_branch2c", b1, 1, 1, 256, true, x, "res2b");
+        NEED(r2b);
+        r = conv("res2c_branch2c", b2, 1, 1, 256, true, r2b, "res2c");
         NEED(r);
     }
     r = proj("res3a", r, 128, 512, 2);
