@@ -115,9 +115,9 @@ def roofline(tim, nprof, precision, images_frac=1.0):
     flops = tim["conv_flops"] * images_frac            # algorithmic FLOPs of the live launch plan (2 * MAC)
     launches = tim["conv_launches"]
     achieved = flops / (conv_ms * 1e-3) / 1e12
-    sfx = "" if precision == "fp32" else "_bf16"
-    traffic_frame, tfile = committed("_traffic%s.json" % sfx, "hbm_bytes_per_frame")
-    rocprof_us, rfile = committed("_conv_roofline%s.json" % sfx, "conv_avg_us_per_launch")
+    pre = "" if precision == "fp32" else "_bf16"   # tools/profile_round.sh r02 / r02_bf16 -> r02_traffic.json / r02_bf16_traffic.json
+    traffic_frame, tfile = committed("%s_traffic.json" % pre, "hbm_bytes_per_frame")
+    rocprof_us, rfile = committed("%s_conv_roofline.json" % pre, "conv_avg_us_per_launch")
     peak = PEAK_FP32_MFMA if precision == "fp32" else PEAK_BF16_MFMA
     first_last = {"avg_launch_us": round(exec_ms * 1e3 / launches, 3),
                   "achieved": round(flops / (exec_ms * 1e-3) / 1e12, 3),
