@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace vnect {
 
@@ -85,6 +86,110 @@ __device__ __forceinline__ void bload_lds(srd_t, float*, unsigned, unsigned) {}
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
+// Second GEMM of a TAIL launch (see the kernel): out[64][tail_n] = mid[64][64] x tail_w^T + tail_bias + shortcut, ReLU, for the
+// 64 rows m0 .. of this workgroup.  mid (the first layer's relu(acc + bias) tile) is in LDS at `smem`, row stride TAIL_MS.
+// The output is 2 row halves x tail_n / 32 column blocks of 32 x 32 (K = 64 each, in the K order of the stand-alone 1x1
+// layer).  All eight waves of the workgroup take part: a CONSUMER wave (wm, g) takes column block g, a PRODUCER wave (wm, g) the
+// blocks 2 + g, 4 + g, ... -- three times as many, because a producer wave has registers to spare while the first GEMM runs: it
+// requests the shortcut values of its first two blocks and the weight fragments of its first block BEFORE the K loop, so the
+// shortcut read (half of this layer's bytes) overlaps the first GEMM's MFMA phase instead of following it.
+template <bool BF>
+constexpr int TAIL_MS = BF ? 72 : 68;  // mid row stride in elements: 144 B (bf16) / 272 B (fp32), conflict-free 16-byte reads
+template <bool BF>
+struct TailRegs {
+    static constexpr int NQ = BF ? 4 : 8;  // MFMA groups over K = 64: 4 x (k = 16) bf16 / 8 x 4 x (k = 2) fp32
+    unsigned rw[2][16];                    // shortcut values of two blocks, as loaded (fp32 bits or a zero-extended bf16)
+    f32x4 Bf[NQ];                          // weight fragments of one block
+};
+// shortcut values of column block cb for the lane's 16 rows (mb = first row of the lane's C/D map)
+template <bool BF>
+__device__ __forceinline__ void tail_load_resid(const ConvArgs& a, int mb, int cb, int lane, unsigned (&rw)[16])
+{
+    const unsigned off = (unsigned)(mb * a.ldr + cb * 32 + (lane & 31));
+    if constexpr (BF) {
+        typedef __attribute__((address_space(1))) const unsigned short cgu16;
+        cgu16* rp = (cgu16*)a.resid;
+#pragma unroll
+        for (int r = 0; r < 16; r++) rw[r] = rp[off], rp += ((r & 3) == 3 ? 5 : 1) * a.ldr;
+    } else {
+        typedef __attribute__((address_space(1))) const unsigned cgu32;
+        cgu32* rp = (cgu32*)a.resid;
+#pragma unroll
+        for (int r = 0; r < 16; r++) rw[r] = rp[off], rp += ((r & 3) == 3 ? 5 : 1) * a.ldr;
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void tail_load_b(const ConvArgs& a, int cb, int lane, f32x4 (&Bf)[TailRegs<BF>::NQ])
+{
+    typedef __attribute__((address_space(1))) const f32x4 cgf4;
+    constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4;  // elements per MFMA group, per lane half
+    const int nrow = cb * 32 + (lane & 31), hh = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < TailRegs<BF>::NQ; q++) {
+        if constexpr (BF) Bf[q] = *(cgf4*)((cgbf16*)a.tail_w + nrow * 64 + UQ * q + UH * hh);
+        else Bf[q] = *(cgf4*)((cgfloat*)a.tail_w + nrow * 64 + UQ * q + UH * hh);
+    }
+}
+// NBLK blocks cb0, cb0 + cbs, ...; PRE: T.rw[0], T.rw[1] (blocks 0, 1) and T.Bf (block 0) were requested by the caller
+template <bool BF, int NBLK, bool PRE>
+__device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, int m0, int wm, int cb0, int cbs, int lane, TailRegs<BF>& T)
+{
+    constexpr int MS = TAIL_MS<BF>, NQ = TailRegs<BF>::NQ;
+    constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4;
+    const int col = lane & 31, hh = lane >> 5;
+    const int mb = m0 + wm * 32 + 4 * hh;  // C/D map: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    f32x4 Af[NQ];
+    f32x16 acc;
+    {
+        const int arow = wm * 32 + col;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if constexpr (BF) Af[q] = *(const f32x4*)((const __bf16*)smem + arow * MS + UQ * q + UH * hh);
+            else Af[q] = *(const f32x4*)(smem + arow * MS + UQ * q + UH * hh);
+        }
+    }
+    if constexpr (!PRE) {
+        tail_load_b<BF>(a, cb0, lane, T.Bf);
+        if (a.resid) tail_load_resid<BF>(a, mb, cb0, lane, T.rw[0]);
+        if (a.resid && NBLK > 1) tail_load_resid<BF>(a, mb, cb0 + cbs, lane, T.rw[1]);
+    }
+    const bool t_of32 = !BF || a.out_f32;
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        const int cb = cb0 + b * cbs, n2 = cb * 32 + col;
+        const float bias2 = ((cgfloat*)a.tail_bias)[n2];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if constexpr (BF) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Af[q]), __builtin_bit_cast(bf16x8, T.Bf[q]), acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[q][e], T.Bf[q][e], acc, 0, 0, 0);
+            }
+        }
+        if (b + 1 < NBLK) tail_load_b<BF>(a, cb + cbs, lane, T.Bf);  // in flight behind this block's epilogue
+        const bool relu2 = cb * 32 < a.relu_cols;                      // uniform per block
+        const unsigned off0 = (unsigned)(mb * a.ldc + n2);
+        gfloat* op = (gfloat*)a.out;
+        unsigned(&rw)[16] = T.rw[b & 1];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float o = acc[r] + bias2;
+            if (a.resid) o = o + __builtin_bit_cast(float, BF ? rw[r] << 16 : rw[r]);
+            if (relu2) o = __builtin_fmaxf(o, 0.f);
+            const unsigned oo = off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * a.ldc);
+            if (n2 < a.Nvalid) {
+                if (t_of32) put_f32(op + oo, o);
+                else put_bf16((gbf16*)op + oo, o);
+            }
+        }
+        if (b + 2 < NBLK && a.resid) tail_load_resid<BF>(a, mb, cb + 2 * cbs, lane, T.rw[b & 1]);  // the slot just consumed
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The conv kernel.  Streaming: a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
 // chunks as one stream through the LDS ring.  The producers simply keep issuing -- the first chunks of the next
 // tile land while the consumers are still in the previous tile's epilogue -- so the per-tile fixed cost (wave
@@ -102,9 +207,10 @@ __device__ __forceinline__ void bload_lds(srd_t, float*, unsigned, unsigned) {}
 // kg-th 128-byte run of every KG*128-byte step, and the groups' accumulators are summed through LDS in group order before
 // the epilogue -- deterministic, no partial slabs in HBM, no second launch.  A step then moves KG*(BM+BN)*128 bytes:
 // 24 KiB for 64x32x2, 32 KiB for 32x32x4, which the LDS-DMA sustains at one workgroup per CU (tools/ring_rate.hip).
-template <int BM, int BN, int KG, int NS, bool BF, int PROF>
+template <int BM, int BN, int KG, int NS, bool BF, int PROF, bool TAIL = false>
 __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
+    static_assert(!TAIL || (BM == 64 && BN == 64 && KG == 1), "the tail GEMM is built for one 64x64 tile per workgroup");
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
@@ -295,6 +401,17 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 default: wait_vm<0>(); break;
             }
         };
+        // TAIL: this wave's share of the second GEMM is column blocks 2 + g, 4 + g, 6 + g, ... of row half wm2; the shortcut values
+        // of the first two and the weight fragments of the first are requested NOW (older than every LDS-DMA below, so the
+        // counted vmcnt waits of the ring are unaffected) and rest in registers this wave does not otherwise need.
+        TailRegs<BF> T;
+        const int wm2 = wave & 1, g2 = wave >> 1;
+        if constexpr (TAIL) {
+            const int mb2 = decode(0).m0 + wm2 * 32 + 4 * (lane >> 5);
+            tail_load_resid<BF>(a, mb2, 2 + g2, lane, T.rw[0]);
+            tail_load_resid<BF>(a, mb2, 4 + g2, lane, T.rw[1]);
+            tail_load_b<BF>(a, 2 + g2, lane, T.Bf);
+        }
         const bool pst = P2 && threadIdx.x == 256 && blockIdx.x == 0;
         if (pst) prof[22] = __builtin_amdgcn_s_memrealtime();  // producer wave 0: arguments pinned, about to decode the first item
         begin_item(0);
@@ -332,6 +449,10 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             pw += q1 - q0, pb += q2 - q1, pi += q3 - q2;
         }
         if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
+        if constexpr (TAIL) {
+            __builtin_amdgcn_s_barrier();  // the consumers have put the layer's tile into LDS (one tile per workgroup)
+            tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
+        }
         return;
     }
 
@@ -415,7 +536,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     const bool fused = h.ksplit == 1;
     const bool direct = (c.os == 1);
     const int col = lane & 31, rhalf = 4 * (lane >> 5);  // C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    cgfloat* resid = fused ? (cgfloat*)c.resid : nullptr;
+    cgfloat* resid = fused && !TAIL ? (cgfloat*)c.resid : nullptr;  // (a tail layer's shortcut belongs to its second GEMM)
     if (pstamp) prof[10] = __builtin_amdgcn_s_memrealtime();
     if constexpr (KG > 1) {
         if (threadIdx.x < (KG - 1) * WMN) ((volatile int*)(smem + SCRATCH + (KG - 1) * WMN * 1024))[threadIdx.x] = 0;
@@ -493,6 +614,39 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             }
         }
 
+        if constexpr (TAIL) {
+            // ---- tail GEMM: out2[64][tail_n] = relu(acc + bias)[64][64] x tail_w^T, + tail_bias + shortcut, ReLU --------------
+            // This workgroup has ONE tile (the host guarantees items <= grid), so its producers are done and the whole ring
+            // is free: every consumer's last real fragment read happened before the final chunk barrier it has just passed.
+            // (a) the tile goes to LDS as the A operand of the second GEMM (row stride 64 + pad: conflict-free 16-byte reads),
+            // (b) all EIGHT waves meet at a barrier -- the producer waves stay for the tail: the second GEMM's blocks are chains of
+            //     dependent memory round trips (weights, shortcut, stores), and eight waves keep twice as many in flight as four --
+            // (c) the 2 x 8 blocks of 32 x 32 (K = 64 each) are shared out as tail_gemm describes: weight fragments straight from
+            //     global memory (64 KB, L2-resident, read in the MFMA's own fragment layout), the next block's fragments in
+            //     flight behind the current block's epilogue, the producers' shortcut values already in registers.
+            // The K order of every output is that of the stand-alone 1x1 layer, and the tile in LDS holds exactly the values
+            // that layer would have read back from HBM: results are bit-identical to the unfused plan.
+            constexpr int MS = TAIL_MS<BF>;
+            const int wm2 = wave & 1, g2 = wave >> 1;  // this wave's share of the tail: row half, column block
+            {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias));  // the layer's own bias (requested before the K loop)
+                const int k1 = wn * 32 + col;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = wm * 32 + rhalf + (r & 3) + 8 * (r >> 2);
+                    const float v = __builtin_fmaxf(acc[r] + bias, 0.f);
+                    if constexpr (BF) ((__bf16*)smem)[row * MS + k1] = (__bf16)v;
+                    else smem[row * MS + k1] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            {
+                TailRegs<BF> T;
+                tail_gemm<BF, 1, false>(a, smem, it.m0, wm2, g2, 0, lane, T);
+            }
+            break;  // one tile per workgroup: nothing of the K-loop state (prefetched fragments, item bookkeeping) lives on
+        }
         // epilogue from registers.  One explicit wait for the bias / shortcut values requested before the K loop, with
         // the values passed through it: otherwise the compiler re-waits (vmcnt(0)) for those loads before every use,
         // i.e. after every store below, and the 16 stores complete one by one (measured: 2.5-4.8 us per epilogue).
@@ -623,6 +777,23 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     static const bool detail = getenv("VNECT_PROF_DETAIL") && atoi(getenv("VNECT_PROF_DETAIL")) != 0;
     const int prof = a.prof ? (detail ? 2 : 1) : 0;
 #define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a)
+    if constexpr (BM == 64 && BN == 64 && KG == 1) {
+        if (a.tail_n > 0) {  // tail GEMM variant: one tile per workgroup, start / end stamps at most
+            if (a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias)
+                return hipErrorInvalidValue;
+#define LAUNCH_TAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, BF, PR, true>), grid, dim3(512), lds, st, a)
+            if (a.bf16) {
+                if (prof == 0) LAUNCH_TAIL(true, 0);
+                else LAUNCH_TAIL(true, 1);
+            } else {
+                if (prof == 0) LAUNCH_TAIL(false, 0);
+                else LAUNCH_TAIL(false, 1);
+            }
+#undef LAUNCH_TAIL
+            return hipGetLastError();
+        }
+    }
+    if (a.tail_n > 0) return hipErrorInvalidValue;
     if (a.bf16) {
         if (prof == 0) LAUNCH_STREAM(true, 0);
         else if (prof == 1) LAUNCH_STREAM(true, 1);
@@ -640,9 +811,14 @@ template <int BM, int BN, int KG, int NS>
 static hipError_t setup_stream()
 {
     hipFuncAttributes fa;
-    for (const void* f : {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 0>,
-                          (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 1>,
-                          (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>}) {
+    std::vector<const void*> fns = {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 0>,
+                                    (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 1>,
+                                    (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>};
+    if constexpr (BM == 64 && BN == 64 && KG == 1) {
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, true>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, true>);
+    }
+    for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());
         if (e != hipSuccess) return e;
         e = hipFuncGetAttributes(&fa, f);

@@ -56,6 +56,13 @@ struct ConvArgs {
     // with scalar shifts -- no table in the argument block, no dependent scalar load per tap
     unsigned long long dy_pack, dx_pack;
     int tapgrid;  // 1: single tap (0,0); 3: the 3x3 grid with pad 1 (validity masks in closed form); 0: walk the table
+    // Tail GEMM (conv_stream_kernel<..., TAIL = true>; 64x64 tiles, ONE tile per workgroup, N = 64): the layer's own output never
+    // reaches HBM -- relu(acc + bias) stays in LDS as a 64 x 64 tile and feeds a 1x1 conv `tail_w` ([tail_n][64], K contiguous)
+    // whose bias / shortcut / ReLU / output are the fields `tail_bias`, resid, relu_cols, out, ldc, Nvalid above describe.
+    // (res2*_branch2b -> res2*_branch2c, vnect_model.py:38-41,50-53,56-59.)
+    const float* tail_w;
+    const float* tail_bias;
+    int tail_n;   // 0: no tail; else the 1x1 conv's output channels (256: 2 row halves x 8 column blocks over the 8 waves)
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

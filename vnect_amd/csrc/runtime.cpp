@@ -598,6 +598,59 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     return L.out;
 }
 
+// A 3x3 conv whose 64 output channels feed a 1x1 conv (+ shortcut + ReLU) of the same pixels -- res2*_branch2b -> res2*_branch2c,
+// vnect_model.py:38-41,50-53,56-59 -- as ONE launch: the 3x3 layer's tile stays in LDS and the 1x1 layer is a second GEMM
+// inside the workgroup (conv.hip, TAIL).  Possible where a workgroup owns ALL of the 3x3 layer's channels for its rows (N = 64:
+// the 92x92 stage) and has one tile (so the ring is free behind the K loop): ceil(M / 64) <= 512 workgroups.  Results are
+// bit-identical to the two stand-alone launches.  Returns the block output tensor or -1; *fits = false if the shape does not
+// admit the fusion (the caller then builds the two layers).
+int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc, int in, int resid, const std::string& out_name,
+                  int mid, int cout, bool* fits)
+{
+    const Tensor tin = h->tensors[in];
+    const int EPR = h->bf16 ? 64 : 32;
+    *fits = mid == 64 && cout == 256 && tin.Cs % EPR == 0 && ((long long)tin.S * tin.H * tin.W + 63) / 64 <= 512 &&
+            !h->keep_activations && !getenv("VNECT_NO_TAIL");
+    if (!*fits) return -1;
+    const int cin = tin.C;
+    const HostArray* Wb = get_w(h, sb + "/weights", {3, 3, cin, mid});
+    const HostArray* Bb = Wb ? get_w(h, sb + "/biases", {mid}) : nullptr;
+    const HostArray* Wc = Bb ? get_w(h, sc + "/weights", {1, 1, mid, cout}) : nullptr;
+    const HostArray* Bc = Wc ? get_w(h, sc + "/biases", {cout}) : nullptr;
+    if (!Bc) return -1;
+    int ho, wo, pt = 0, pl = 0;
+    same_pad(tin.H, 3, 1, &ho, &pt), same_pad(tin.W, 3, 1, &wo, &pl);
+    Layer L;
+    L.op = OP_CONV, L.name = sb + ">" + sc, L.in = in, L.resid = resid;
+    L.out = add_tensor(h, out_name, tin.S, ho, wo, cout, cout);
+    ConvArgs& a = L.a;
+    a.S = tin.S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
+    a.Ho = ho, a.Wo = wo, a.M = tin.S * ho * wo, a.stride = 1;
+    a.OH = ho, a.OW = wo, a.os = 1, a.nphase = 1;
+    a.ldc = cout, a.ldr = cout, a.relu_cols = cout, a.Nvalid = cout;  // the TAIL's output, shortcut and ReLU
+    a.bf16 = h->bf16;
+    a.ntaps = 9, a.cpt = tin.Cs / EPR, a.K = 9 * tin.Cs;
+    for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) L.dy[ky * 3 + kx] = ky - pt, L.dx[ky * 3 + kx] = kx - pl;
+    L.Nreal = mid, L.Kreal = 9 * cin;
+    L.flops = 2.0 * a.M * ((double)L.Kreal * mid + (double)mid * cout);
+    L.BM = 64, L.BN = 64, L.KG = 1, a.ksplit = 1;
+    a.Npad = 64;
+    std::vector<float> wp((size_t)64 * a.K, 0.f), bp(64, 0.f), w2((size_t)cout * 64, 0.f), b2(cout, 0.f);
+    for (int t = 0; t < 9; t++)
+        for (int ci = 0; ci < cin; ci++)
+            for (int n = 0; n < mid; n++) wp[(size_t)n * a.K + (size_t)t * tin.Cs + ci] = Wb->d[((size_t)t * cin + ci) * mid + n];
+    for (int n = 0; n < mid; n++) bp[n] = Bb->d[n];
+    for (int k = 0; k < mid; k++)
+        for (int n = 0; n < cout; n++) w2[(size_t)n * 64 + k] = Wc->d[(size_t)k * cout + n];
+    for (int n = 0; n < cout; n++) b2[n] = Bc->d[n];
+    float *dw2 = nullptr, *db2 = nullptr;
+    if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
+    a.tail_w = dw2, a.tail_bias = db2, a.tail_n = cout;
+    h->layers.push_back(L);
+    return L.out;
+}
+
 // point a conv layer's arguments at h's activation buffers and workspace (weights are whatever L already holds)
 void bind_activations(vnect_handle* h, Layer& L)
 {
@@ -651,27 +704,60 @@ int finalize_impl(vnect_handle* h)
         int b = a < 0 ? -1 : conv(p + "_branch2b", a, 3, 1, mid, true);
         return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, x, p);
     };
-    int r = proj("res2a", pool1, 64, 256, 1);
-    NEED(r);
+    // 92x92 stage: each block's 3x3 layer has 64 channels, i.e. one 64-wide tile column, so its 1x1 successor can run as a tail
+    // GEMM of the same workgroups (add_conv_tail): 3 launches and 3 x 13 MB of intermediate traffic fewer.  Where the shape does
+    // not admit it (more than 512 tiles: four or more scales; per-layer read-back requested) the stand-alone layers run, and in
+    // the reference's wiring res2b_branch2b / res2c_branch2b -- both read res2b_branch2a -- share one dual-output launch.
+    int r;
+    {
+        int s = -1;
+        int a = add_conv_pair(h, "res2a_branch2a", 64, "res2a_branch1", 256, pool1, 1, &s);
+        NEED(a);
+        bool fits = false;
+        r = add_conv_tail(h, "res2a_branch2b", "res2a_branch2c", a, s, "res2a", 64, 256, &fits);
+        if (!fits) {
+            int b = conv("res2a_branch2b", a, 3, 1, 64, true);
+            NEED(b);
+            r = conv("res2a_branch2c", b, 1, 1, 256, true, s, "res2a");
+        }
+        NEED(r);
+    }
     if (h->cfg.paper_res2c) {
-        r = ident("res2b", r, 64, 256);
-        NEED(r);
-        r = ident("res2c", r, 64, 256);
-        NEED(r);
+        for (const char* p : {"res2b", "res2c"}) {
+            const std::string P = p;
+            int a = conv(P + "_branch2a", r, 1, 1, 64, true);
+            NEED(a);
+            bool fits = false;
+            int o = add_conv_tail(h, P + "_branch2b", P + "_branch2c", a, r, P, 64, 256, &fits);
+            if (!fits) {
+                int b = conv(P + "_branch2b", a, 3, 1, 64, true);
+                NEED(b);
+                o = conv(P + "_branch2c", b, 1, 1, 256, true, r, P);
+            }
+            NEED(o);
+            r = o;
+        }
     } else {
-        // vnect_model.py:50-57: res2c_branch2b consumes res2b_branch2a (`:56`), res2c_branch2a is dead and pruned -- so the two
-        // 3x3 convs res2b_branch2b and res2c_branch2b read the SAME tensor and run as one dual-output launch
+        // vnect_model.py:50-57: res2c_branch2b consumes res2b_branch2a (`:56`), res2c_branch2a is dead and pruned
         if (!get_w(h, "res2c_branch2a/weights", {1, 1, 256, 64})) return VNECT_E_ARG;  // schema completeness, like the reference's load_weights
         const int x = r;
         int a = conv("res2b_branch2a", x, 1, 1, 64, true);
         NEED(a);
-        int b2 = -1;
-        int b1 = add_conv_pair(h, "res2b_branch2b", 64, "res2c_branch2b", 64, a, 1, &b2, 3, true);
-        NEED(b1);
-        int r2b = conv("res2b_branch2c", b1, 1, 1, 256, true, x, "res2b");
-        NEED(r2b);
-        r = conv("res2c_branch2c", b2, 1, 1, 256, true, r2b, "res2c");
-        NEED(r);
+        bool fits = false;
+        int r2b = add_conv_tail(h, "res2b_branch2b", "res2b_branch2c", a, x, "res2b", 64, 256, &fits);
+        if (fits) {
+            NEED(r2b);
+            r = add_conv_tail(h, "res2c_branch2b", "res2c_branch2c", a, r2b, "res2c", 64, 256, &fits);
+            NEED(r);
+        } else {
+            int b2 = -1;
+            int b1 = add_conv_pair(h, "res2b_branch2b", 64, "res2c_branch2b", 64, a, 1, &b2, 3, true);
+            NEED(b1);
+            r2b = conv("res2b_branch2c", b1, 1, 1, 256, true, x, "res2b");
+            NEED(r2b);
+            r = conv("res2c_branch2c", b2, 1, 1, 256, true, r2b, "res2c");
+            NEED(r);
+        }
     }
     r = proj("res3a", r, 128, 512, 2);
     NEED(r);
