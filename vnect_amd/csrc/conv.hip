@@ -86,6 +86,46 @@ __device__ __forceinline__ void bload_lds(srd_t, float*, unsigned, unsigned) {}
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
+// Bone-length features (vnect_model.py:198-209) inside the transposed conv's launch (FUSE = 2): the tile with output columns
+// 128 .. 191 holds delta_x (128 + j), delta_y (149 + j), delta_z (170 + j), j < 21; its accumulators are in LDS ([64 rows][BONE_LS]),
+// and the four producer waves (256 threads) write bone_j = sqrt((dx^2 + dy^2) + dz^2) to column 191 + j of every row's output
+// pixel and zeros to the padding columns 212 .. ldc - 1, exactly what bone_kernel does as a launch of its own.
+constexpr int BONE_N0 = 128, BONE_LS = 68;
+__device__ __forceinline__ float bone_len(float x, float y, float z)
+{
+#pragma clang fp contract(off)
+    return sqrtf((x * x + y * y) + z * z);  // one rounding per operation, in both the fused and the stand-alone form
+}
+template <bool BF>
+__device__ __forceinline__ void bone_features(const ConvArgs& a, const float* t, int m0, int phase, int tid, int M, int Wo, int Ho,
+                                              unsigned mg_wo, unsigned mg_ho)
+{
+    const int py = phase >> 1, px = phase & 1;
+    const int npad = a.ldc - 212;  // padding columns behind the 212 features
+    auto pixel = [&](int m) {
+        const int q = fdiv(m, mg_wo, Wo), ox = m - q * Wo;
+        const int sI = fdiv(q, mg_ho, Ho), oy = q - sI * Ho;
+        return (sI * a.OH + oy * a.os + py) * a.OW + ox * a.os + px;
+    };
+    // thread -> (row = tid >> 2, quarter = tid & 3): a row's 21 + npad columns are walked by 4 threads; the row's output pixel
+    // is computed once
+    const int row = tid >> 2, m = m0 + row;
+    if (m >= M) return;
+    const unsigned base = (unsigned)(pixel(m) * a.ldc + 191);
+    const float* tr = t + row * BONE_LS;
+    for (int j = tid & 3; j < 21 + npad; j += 4) {
+        float v = 0.f;
+        if (j < 21) {
+            float x = tr[j], y = tr[21 + j], z = tr[42 + j];
+            if constexpr (BF) x = (float)(__bf16)x, y = (float)(__bf16)y, z = (float)(__bf16)z;  // what the stand-alone kernel reads back
+            v = bone_len(x, y, z);
+        }
+        if constexpr (BF) put_bf16((gbf16*)a.out + base + j, v);
+        else put_f32((gfloat*)a.out + base + j, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Second GEMM of a TAIL launch (see the kernel): out[64][tail_n] = mid[64][64] x tail_w^T + tail_bias + shortcut, ReLU, for the
 // 64 rows m0 .. of this workgroup.  mid (the first layer's relu(acc + bias) tile) is in LDS at `smem`, row stride TAIL_MS.
 // The output is 2 row halves x tail_n / 32 column blocks of 32 x 32 (K = 64 each, in the K order of the stand-alone 1x1
@@ -207,10 +247,14 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
 // kg-th 128-byte run of every KG*128-byte step, and the groups' accumulators are summed through LDS in group order before
 // the epilogue -- deterministic, no partial slabs in HBM, no second launch.  A step then moves KG*(BM+BN)*128 bytes:
 // 24 KiB for 64x32x2, 32 KiB for 32x32x4, which the LDS-DMA sustains at one workgroup per CU (tools/ring_rate.hip).
-template <int BM, int BN, int KG, int NS, bool BF, int PROF, bool TAIL = false>
+// FUSE: what else the launch does behind a tile's K loop, in the LDS ring that a workgroup with ONE tile no longer needs by then
+// (the host guarantees items <= grid): 1 = TAIL, a 1x1 conv on the tile as a second GEMM (tail_gemm); 2 = BONE, the bone-length
+// features of vnect_model.py:198-209 from the transposed conv's delta columns (bone_features).
+template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0>
 __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
-    static_assert(!TAIL || (BM == 64 && BN == 64 && KG == 1), "the tail GEMM is built for one 64x64 tile per workgroup");
+    constexpr bool TAIL = FUSE == 1, BONE = FUSE == 2;
+    static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1), "the fused forms are built for one 64x64 tile per workgroup");
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
@@ -453,6 +497,13 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             __builtin_amdgcn_s_barrier();  // the consumers have put the layer's tile into LDS (one tile per workgroup)
             tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
         }
+        if constexpr (BONE) {
+            const Item it0 = decode(0);
+            if (it0.n0 == BONE_N0) {  // the tile that holds the 63 delta columns (uniform per workgroup)
+                __builtin_amdgcn_s_barrier();  // ... is in LDS now
+                bone_features<BF>(a, smem, it0.m0, it0.phase, tid, h.M, h.Wo, h.Ho, h.mg_wo, h.mg_ho);
+            }
+        }
         return;
     }
 
@@ -614,6 +665,17 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             }
         }
 
+        if constexpr (BONE) {
+            if (it.n0 == BONE_N0) {
+                // the 63 delta columns of this row block (no bias, no BN on these columns: the accumulators ARE the values the
+                // epilogue below stores) go to LDS for the producer waves, which have nothing left to do and compute the
+                // bone lengths from them while this wave runs its ordinary epilogue
+#pragma unroll
+                for (int r = 0; r < 16; r++) smem[(wm * 32 + rhalf + (r & 3) + 8 * (r >> 2)) * BONE_LS + wn * 32 + col] = acc[r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
         if constexpr (TAIL) {
             // ---- tail GEMM: out2[64][tail_n] = relu(acc + bias)[64][64] x tail_w^T, + tail_bias + shortcut, ReLU --------------
             // This workgroup has ONE tile (the host guarantees items <= grid), so its producers are done and the whole ring
@@ -781,7 +843,7 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
         if (a.tail_n > 0) {  // tail GEMM variant: one tile per workgroup, start / end stamps at most
             if (a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias)
                 return hipErrorInvalidValue;
-#define LAUNCH_TAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, BF, PR, true>), grid, dim3(512), lds, st, a)
+#define LAUNCH_TAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, BF, PR, 1>), grid, dim3(512), lds, st, a)
             if (a.bf16) {
                 if (prof == 0) LAUNCH_TAIL(true, 0);
                 else LAUNCH_TAIL(true, 1);
@@ -794,6 +856,22 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
         }
     }
     if (a.tail_n > 0) return hipErrorInvalidValue;
+    if constexpr (BM == 64 && BN == 64 && KG == 1) {
+        if (a.bone) {  // bone-length features inside the transposed conv's launch: one tile per workgroup again
+            if (a.items > maxwg || a.ksplit != 1 || a.Npad != 192 || a.ldc < 212) return hipErrorInvalidValue;
+#define LAUNCH_BONE(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, BF, PR, 2>), grid, dim3(512), lds, st, a)
+            if (a.bf16) {
+                if (prof == 0) LAUNCH_BONE(true, 0);
+                else LAUNCH_BONE(true, 1);
+            } else {
+                if (prof == 0) LAUNCH_BONE(false, 0);
+                else LAUNCH_BONE(false, 1);
+            }
+#undef LAUNCH_BONE
+            return hipGetLastError();
+        }
+    }
+    if (a.bone) return hipErrorInvalidValue;
     if (a.bf16) {
         if (prof == 0) LAUNCH_STREAM(true, 0);
         else if (prof == 1) LAUNCH_STREAM(true, 1);
@@ -815,8 +893,10 @@ static hipError_t setup_stream()
                                     (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 1>,
                                     (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>};
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
-        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, true>);
-        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, true>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 1>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 1>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 2>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 2>);
     }
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());
@@ -948,7 +1028,7 @@ __global__ void bone_kernel(T* feat, long long npix, int ld)
     float v = 0.f;
     if (j < 21) {
         float x = (float)f[128 + j], y = (float)f[149 + j], z = (float)f[170 + j];
-        v = sqrtf((x * x + y * y) + z * z);
+        v = bone_len(x, y, z);
     }
     f[191 + j] = (T)v;
 }

@@ -842,10 +842,19 @@ int finalize_impl(vnect_handle* h)
         }
         if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
             return VNECT_E_HIP;
+        // bone-length features (vnect_model.py:198-209): inside this launch (conv.hip, FUSE = 2) where every workgroup has one tile,
+        // i.e. up to 5 scales; as a launch of their own otherwise, and when per-layer read-back is requested
+        const long long deconv_items = (long long)((a.M + 63) / 64) * (a.Npad / 64) * 4;
+        const bool fuse_bone = L.BM == 64 && L.BN == 64 && L.KG == 1 && a.ksplit == 1 && deconv_items <= 512 && !h->keep_activations &&
+                               !getenv("VNECT_NO_BONE_FUSE");
+        a.bone = fuse_bone;
+        if (fuse_bone) L.name = "res5c_deconv+bone_length";
         h->layers.push_back(L);
-        Layer Bn;
-        Bn.op = OP_BONE, Bn.name = "res5c_bone_length", Bn.in = feat, Bn.out = feat;
-        h->layers.push_back(Bn);
+        if (!fuse_bone) {
+            Layer Bn;
+            Bn.op = OP_BONE, Bn.name = "res5c_bone_length", Bn.in = feat, Bn.out = feat;
+            h->layers.push_back(Bn);
+        }
     }
     // head (vnect_model.py:211-217)
     int hd = conv("res5c_branch2b", feat, 3, 1, 128, true);
