@@ -188,9 +188,14 @@ def main():
     from vnect_amd.parallel import Group, PyramidJob, aggregate_rate, stream_seed
     from vnect_amd.weights import synthetic_weights
 
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    grp = Group("nccl")
-    rank, local_rank = grp.rank, grp.local_rank
+    # Rehearsal on a ONE-GPU box (never the measured configuration): VNECT_BENCH_DEVICE=0 puts every rank on device 0 and
+    # VNECT_BENCH_BACKEND=gloo carries the barrier / max-reduce over the CPU (RCCL refuses two ranks on one device)
+    backend = os.environ.get("VNECT_BENCH_BACKEND", "nccl")
+    dev_override = os.environ.get("VNECT_BENCH_DEVICE")
+    torch.cuda.set_device(int(dev_override if dev_override is not None else os.environ.get("LOCAL_RANK", "0")))
+    grp = Group(backend)
+    rank = grp.rank
+    local_rank = int(dev_override) if dev_override is not None else grp.local_rank
     weights = synthetic_weights()
     nslots = 8
 
