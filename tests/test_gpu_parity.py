@@ -242,6 +242,27 @@ def test_four_scales_whole_path(weights, oracle_net):
     h.close()
 
 
+def test_six_scales_take_the_unfused_plans(weights, oracle_net):
+    """The fused forms of the conv launch (tail GEMM at 92x92, bone features inside the transposed conv) need one tile per
+    workgroup; with six scales the 92x92 layers have 794 tiles and the transposed conv 600 items, so the stand-alone layers, the
+    dual-output 3x3 launch and the bone kernel run instead (and every tile streams).  Same tolerance against the oracle, and the
+    five-scale handle (fused transposed conv, unfused 92x92) agrees too."""
+    import oracle
+    from tests import helpers
+    frame = helpers.synth_frame(2024, 300, 368, smooth=True)
+    for scales in ([1.0, 0.95, 0.9, 0.8, 0.7, 0.6], [1.0, 0.9, 0.8, 0.7, 0.6]):
+        h = _handle(scales, weights)
+        names = [L["name"] for L in h.layers()]
+        assert "res2b_branch2b+res2c_branch2b" in names and not any(">" in n for n in names), names
+        assert ("res5c_bone_length" in names) == (len(scales) == 6), names
+        rb, _, _ = oracle.gen_input_batch(frame, scales)
+        b, _, _ = h.preprocess(frame)
+        assert np.array_equal(b, rb)
+        out, ref = h.forward(b), oracle_net.forward(rb)
+        assert float(np.abs(out - ref).max()) <= 1e-4 * float(np.abs(ref).max()), len(scales)
+        h.close()
+
+
 @pytest.mark.parametrize("promo", [0, 1])
 def test_postprocess_long_filter_chain(weights, promo):
     """The OneEuro state is a recurrence: 150 frames of moving peaks (a drifting mixture of 5 map sets, so every joint's
