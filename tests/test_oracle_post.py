@@ -137,3 +137,31 @@ def test_extract_2d_planted_peaks():
     for j in range(21):
         up = np_resize(np.ascontiguousarray(noisy[:, :, j]), 8.0)
         assert tuple(j2[j]) == np.unravel_index(np.argmax(up), up.shape)
+
+
+def test_float_resize_agrees_with_torch_bilinear():
+    """An implementation nobody here wrote: torch's CPU bilinear kernel (align_corners=False, no antialias) uses the same
+    half-pixel formula as cv2.resize(INTER_LINEAR) -- src = (d + 0.5) * (1 / f) - 0.5, clamped at 0, second tap clamped at the
+    last sample -- wherever the two agree on the OUTPUT SIZE (torch floors size * f, cv2 rounds it).  That covers the x8
+    up-sampling of utils.extract_2d_joints (46 -> 368, float64: same taps and weights -- multiples of 1/16 -- and only the order
+    of the two lerps differs, so the results agree to an ulp or two) and the 1 / 0.85 re-scaling of the reference's default pyramid (46 -> 54, float32).  cv2 itself cannot be run
+    here (parity unpinned); this pins the restated formula against a third party at least."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.RandomState(11)
+    m = rng.standard_normal((46, 46)).astype(np.float64)
+    up = oracle.resize(m, 8.0)
+    t = F.interpolate(torch.from_numpy(m)[None, None], scale_factor=8.0, mode="bilinear", align_corners=False,
+                      recompute_scale_factor=False)[0, 0].numpy()
+    assert up.shape == t.shape == (368, 368)
+    assert float(np.abs(up - t).max()) <= 4 * np.finfo(np.float64).eps * float(np.abs(m).max())   # measured: 1 ulp
+    assert np.array_equal(up[:, :4], np.repeat(up[:, :1], 4, axis=1)) and np.array_equal(t[:, :4], np.repeat(t[:, :1], 4, axis=1))  # left clamp: d < 4 -> sample 0
+    m32 = rng.standard_normal((46, 46, 21)).astype(np.float32)
+    f = 1.0 / 0.85
+    a = oracle.resize(m32, f)
+    t = F.interpolate(torch.from_numpy(m32).permute(2, 0, 1)[None], scale_factor=f, mode="bilinear", align_corners=False,
+                      recompute_scale_factor=False)[0].permute(1, 2, 0).numpy()
+    assert a.shape == t.shape == (54, 54, 21)
+    # same taps and the same float32 weights up to the order of the two lerps (cv2: horizontal first; torch: one fused
+    # expression): a few ulp of the blended values
+    assert float(np.abs(a - t).max()) <= 1e-5 * float(np.abs(m32).max())   # measured: 6e-6
