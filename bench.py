@@ -161,7 +161,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches everywhere")
+    ap.add_argument("--graph", action="store_true", help="replay the frame graph for synchronous frames too (default: auto = eager "
+                                                        "launches for a synchronous frame, graph replay when frames are in flight)")
     ap.add_argument("--no-aux", action="store_true",
                     help="skip the auxiliary legs (PCIe-inclusive, frames in flight, two streams per GPU, the bf16 leg): a rocprofv3 "
                          "run meant to describe the synchronous headline loop of ONE precision uses this")
@@ -206,6 +208,7 @@ def main():
         h.finalize()
         return h
 
+    graph_mode = False if args.no_graph else (True if args.graph else "auto")
     job = None
     if args.pyramid:
         if args.gpus != len(SCALES):
@@ -215,7 +218,7 @@ def main():
         h = job.handle
     else:
         # lanes=3: the extra lanes only ever run frames submitted while others are in flight (the pipelined leg below)
-        h = make(args.precision, use_graph=not args.no_graph, lanes=3)
+        h = make(args.precision, use_graph=graph_mode, lanes=3)
     # replicas: one synthetic video stream per rank, seeds 1234 + 1000*stream;
     # pyramid: every rank sees the SAME stream 0
     stream = 0 if args.pyramid else rank
@@ -285,7 +288,7 @@ def main():
         # launches of one synchronous stream are worth.  Reported beside the headline, never as `value`.
         if rank == 0:
             import threading
-            h2 = make(args.precision, use_graph=not args.no_graph)
+            h2 = make(args.precision, use_graph=graph_mode)
             for k in range(nslots):
                 h2.upload_frame(k, helpers.synth_frame(stream_seed(rank + 1000, k)))
 
@@ -327,7 +330,9 @@ def main():
                                    % (("fp32", 1) if args.precision == "fp32" else ("bf16 operands, fp32 accumulate", 2)),
                        "weights": "seeded synthetic (reference ships none)", "frames_resident_in_hbm": True,
                        "h2d_in_timed_region": False,
-                       "hip_graph": not args.no_graph, "sync_per_frame": True,
+                       "hip_graph": {False: "off (eager launches)", True: "on (every frame replays the graph)",
+                                     "auto": "auto: eager launches for a synchronous frame, graph replay when frames are in flight"}[graph_mode],
+                       "sync_per_frame": True,
                        "parallelism": ("pyramid: 1 scale per GPU + one %s exchange of the maps per frame"
                                        % ("RCCL all-gather" if args.exchange == "rccl" else "peer-write (xGMI)"))
                                       if args.pyramid else "stream replicas"},
@@ -343,7 +348,7 @@ def main():
     # BASELINE.json configs[2] in the same record: the bf16 MFMA conv path, measured exactly like the headline (same frames,
     # same warm-up / steps / barriers), after the fp32 timed region.  N=1 only; never `value`.
     if args.gpus == 1 and args.precision == "fp32" and not args.no_aux and not args.pyramid:
-        hb = make("bf16", use_graph=not args.no_graph)
+        hb = make("bf16", use_graph=graph_mode)
         for k in range(nslots):
             hb.upload_frame(k, host_frames[k])
         eb, latb = timed(hb, args.steps, args.warmup)

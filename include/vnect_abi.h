@@ -52,7 +52,9 @@ typedef struct vnect_config {
     double scales[VNECT_MAX_SCALES];  /* each in (0, 1]                                           */
     int32_t precision;                /* VNECT_FP32 | VNECT_BF16                                  */
     int32_t paper_res2c;              /* 0 = reference wiring src/vnect_model.py:56 (default)     */
-    int32_t use_graph;                /* 1 = replay the frame as one hipGraph                     */
+    int32_t use_graph;                /* 0 = eager launches; 1 = replay the frame as one hipGraph;
+                                         2 = auto: eager for a frame submitted while none is in flight
+                                         (synchronous use), graph replay behind frames in flight    */
     int32_t numpy_promotion;          /* float32-fed 3-D filters: 0 = numpy 1.x rules (the only
                                          numpy TF1 runs with), 1 = NEP 50 (numpy >= 2)            */
     int32_t max_frame_bytes;          /* capacity of one resident frame slot; 0 -> 4096*4096*3     */

@@ -112,7 +112,7 @@ def _ptr(a, t):
 class Handle:
     """Thin RAII wrapper over vnect_handle; every method maps 1:1 to a C entry point."""
 
-    def __init__(self, scales, device=0, precision=FP32, paper_res2c=False, use_graph=True, numpy_promotion=0,
+    def __init__(self, scales, device=0, precision=FP32, paper_res2c=False, use_graph="auto", numpy_promotion=0,
                  max_frame_bytes=0, num_frame_slots=0, pyramid=None, keep_activations=False, lanes=1,
                  preprocess_only=False, exchange=XCHG_RCCL):
         L = lib()
@@ -122,7 +122,9 @@ class Handle:
         cfg.num_scales = len(scales)
         for i, s in enumerate(scales):
             cfg.scales[i] = float(s)
-        cfg.precision, cfg.paper_res2c, cfg.use_graph = precision, int(paper_res2c), int(use_graph)
+        # use_graph: False = eager launches, True = always replay the frame graph, "auto" = eager for a synchronous frame,
+        # graph replay when frames are in flight (the default)
+        cfg.precision, cfg.paper_res2c, cfg.use_graph = precision, int(paper_res2c), (2 if use_graph == "auto" else int(bool(use_graph)))
         cfg.numpy_promotion, cfg.max_frame_bytes, cfg.num_frame_slots = numpy_promotion, max_frame_bytes, num_frame_slots
         cfg.lanes = int(lanes)  # 2: submit_resident/collect overlap two frames on two lanes
         cfg.keep_activations = int(keep_activations)  # True: activation(name) can return inner layers (tests)

@@ -25,7 +25,7 @@ class VNectEstimator:
     joint_parents = [16, 15, 1, 2, 3, 1, 5, 6, 14, 8, 9, 14, 11, 12, 14, 14, 1, 4, 7, 10, 13]
 
     def __init__(self, scales=None, weights=None, seed=MASTER_SEED, device=0, precision="fp32", paper_res2c=False,
-                 use_graph=True, numpy_promotion="legacy", verbose=True, lanes=1):
+                 use_graph="auto", numpy_promotion="legacy", verbose=True, lanes=1):
         if verbose:
             print('Initializing VNect Estimator...')
         # src/estimator.py:32; "for faster loops, use less scales e.g. [1], [1, 0.7]"
