@@ -414,6 +414,21 @@ def test_end_to_end_nonsquare_frames(h3, oracle_net):
         e2e.check(frame, t, t + 0.001, j2, j3, h3.activation("res5c_branch2c"), (H, W))
 
 
+@pytest.mark.parametrize("scales", [[1, 0.85, 0.7], [1.0, 0.7], [1.0]])
+def test_end_to_end_reference_default_scales(weights, oracle_net, scales):
+    """Whole __call__ at the reference's own pyramid (estimator.py:32: [1, 0.85, 0.7]) and at the two shorter ones its comment
+    suggests "for faster loops" ([1, 0.7], [1]), on frames of the test picture's size: the every-frame, every-joint gate."""
+    from tests import helpers
+    h = _handle(scales, weights)
+    e2e = _EndToEnd([float(s) for s in scales], oracle_net)
+    for k in range(3):
+        frame = helpers.synth_frame(3100 + k, 538, 368, smooth=True)
+        t = T0 + 200 + k / 30 + 0.002 * k
+        j2, j3 = h.infer(frame, t, t + 0.0013)
+        e2e.check(frame, t, t + 0.0013, j2, j3, h.activation("res5c_branch2c"), (scales, k))
+    h.close()
+
+
 @pytest.mark.parametrize("lanes,graph", [(1, True), (2, True), (2, False), (3, True)])
 def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
     """Two frames in flight (submit k+1 before collecting k) return exactly what one-at-a-time inference returns: on one
