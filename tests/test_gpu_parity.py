@@ -98,6 +98,28 @@ def test_conv_stack_every_layer(h3, weights, oracle_net):
     assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4
 
 
+def test_conv1_span_form_is_bit_identical(weights, oracle_net, monkeypatch):
+    """conv1 (fp32) reads its A operand from the tile's contiguous pixel run(s) instead of 64 gathered windows and skips the MFMAs
+    of the zero padding channel (conv.hip, SPAN): same K order, so conv1 and everything behind it must equal the gathered-window
+    form (VNECT_NO_SPAN=1) bit for bit -- on frames whose tiles straddle output rows and images (S = 1, 2, 3)."""
+    import oracle
+    from tests import helpers
+    for scales in ([1.0], [1.0, 0.7], BASELINE_SCALES):
+        batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(640 + len(scales), 333, 368), scales)
+        h = _handle(scales, weights, keep_activations=True, use_graph=False)
+        out = h.forward(batch)
+        c1 = h.activation("conv1")
+        monkeypatch.setenv("VNECT_NO_SPAN", "1")
+        ref_out = h.forward(batch)
+        ref_c1 = h.activation("conv1")
+        monkeypatch.delenv("VNECT_NO_SPAN")
+        h.close()
+        assert np.array_equal(c1, ref_c1), len(scales)
+        assert np.array_equal(out, ref_out), len(scales)
+        r = oracle_net.forward(batch)
+        assert float(np.abs(out - r).max()) <= 1e-4 * float(np.abs(r).max())
+
+
 def test_conv_stack_batch_independent(h3, oracle_net):
     """The S images are independent: permuting the batch permutes the output (what sharding relies on)."""
     import oracle

@@ -250,17 +250,25 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
 // FUSE: what else the launch does behind a tile's K loop, in the LDS ring that a workgroup with ONE tile no longer needs by then
 // (the host guarantees items <= grid): 1 = TAIL, a 1x1 conv on the tile as a second GEMM (tail_gemm); 2 = BONE, the bone-length
 // features of vnect_model.py:198-209 from the transposed conv's delta columns (bone_features).
-template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0>
+// SPAN (conv1, fp32): the A operand of a chunk is not gathered row by row.  The 64 output pixels of a tile sit in one output row (or
+// in two, where the tile runs over a row's end), and their 8-pixel windows on input row 2 oy + ky - 2 overlap: together they are
+// ONE contiguous run of 2 n + 6 NHWC4 pixels per output row -- 2.2 KB instead of the 8 KB of 64 gathered, 32-byte-aligned (two
+// cache lines each) 128-byte windows, whose LDS-DMA issue paced the round-1 conv1 (0.9 us per chunk against 0.47 us of MFMA).
+// The producers land the run(s) as they lie in memory (three DMA instructions per chunk instead of eight), and a consumer lane
+// reads its fragment at pixel slot 2 row + 2 q + h of the run.  The K order is unchanged; the 16 MFMAs per chunk become 12: channel 3
+// of the NHWC4 input is the zero padding channel (zero weights), so the e = 3 MFMA of every group adds exact zeros.
+template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false>
 __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
     constexpr bool TAIL = FUSE == 1, BONE = FUSE == 2;
+    static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
     static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1), "the fused forms are built for one 64x64 tile per workgroup");
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
     constexpr int ARB = BM / 32, BRB = BN / 32, WMN = ARB * BRB;  // 32-row blocks of A and B; accumulators per K group
     constexpr int ROWS = BM + BN, SUB = ROWS * 32;               // one K group's image: ROWS x 128 B
-    constexpr int STAGE = SUB * KG, NLD = KG * ROWS / 32;        // floats per ring stage; LDS-DMA instructions per producer wave per step
+    constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : KG * ROWS / 32;  // floats per ring stage; LDS-DMA instructions per producer wave per step
     constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x 4 KiB, then WMN*(KG-1) flags
     constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
     static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
@@ -335,6 +343,18 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         }
         return it;
     };
+    // SPAN: rows m0 .. m0 + 63 of a tile = n0 pixels at the end of output row t0 (= s * Ho + oy) + 64 - n0 at the start of row t0 + 1;
+    // their input runs (x' = x + 2, so that the left padding starts at x' = 0) hold c0 = 2 n0 + 6 and 2 (64 - n0) + 6 pixel slots
+    struct SpanGeo {
+        int t0, ox0, n0, c0, c1;
+    };
+    auto span_geo = [&](int m0) __attribute__((always_inline)) {
+        SpanGeo g;
+        g.t0 = __builtin_amdgcn_readfirstlane(fdiv(m0, h.mg_wo, h.Wo)), g.ox0 = m0 - g.t0 * h.Wo;
+        g.n0 = h.Wo - g.ox0 < 64 ? h.Wo - g.ox0 : 64;
+        g.c0 = 2 * g.n0 + 6, g.c1 = g.n0 < 64 ? 2 * (64 - g.n0) + 6 : 0;
+        return g;
+    };
     int G = 0;  // chunks in this workgroup's stream
     if (h.ksplit == 1) G = my_n * nch;
     else
@@ -379,8 +399,28 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         auto begin_item = [&](int j) __attribute__((always_inline)) {
             const Item it = decode(j);
             tb = __builtin_amdgcn_readfirstlane(it.phase * h.ntaps);
+            if constexpr (SPAN) {
+                // lane -> pixel slot 64 wave + lane of the tile's run(s); slots behind the runs (and all of wave 3) land zeros
+                const SpanGeo g = span_geo(it.m0);
+                const int slot = wave * 64 + lane;
+                const int grow = slot < g.c0 ? g.t0 : g.t0 + 1;                  // output row s * Ho + oy the slot belongs to
+                const int xp = slot < g.c0 ? 2 * g.ox0 + slot : slot - g.c0;     // x + 2 of the slot's input pixel
+                const int sI = fdiv(grow, h.mg_ho, h.Ho), oy = grow - sI * h.Ho;
+                const bool live = slot < g.c0 + g.c1 && grow * h.Wo < h.M;       // (the last tile may run past the last image)
+                a_vo[0] = 0, a_mask[0] = 0;
 #pragma unroll
-            for (int i = 0; i < ARB; i++) {
+                for (int i = 1; i < ARB; i++) a_vo[i] = 0, a_mask[i] = 0;
+                if (live) {
+                    const int iy = oy * p.stride, ix = xp;
+                    a_vo[0] = (unsigned)(((sI * p.H + iy) * p.W + ix) * p.Cs * ESZ);
+                    for (int t2 = 0; t2 < h.ntaps; t2++) {
+                        const int y = iy + tap_dy(tb + t2), x = ix + tap_dx(tb + t2);
+                        a_mask[0] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (SPAN ? 0 : ARB); i++) {
                 const int m = it.m0 + srow + 32 * i;
                 a_vo[i] = 0, a_mask[i] = 0;
                 if (m < h.M) {
@@ -420,7 +460,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
 #pragma unroll
             for (int k = 0; k < KG; k++) {  // K group k: the k-th 128-byte run of the step, landed in its own image
 #pragma unroll
-                for (int i = 0; i < ARB; i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
+                for (int i = 0; i < (SPAN ? 1 : ARB); i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
 #pragma unroll
                 for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], uB + k * 128);
             }
@@ -512,16 +552,26 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     int fo[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) fo[q] = (lane & 31) * 32 + (((2 * q + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4);
+    // SPAN: A fragments come from the tile's pixel run(s): row R of the tile starts at slot 2 R of the first run or, behind the
+    // row's end, at slot c0 + 2 (R - n0) of the second; fragment q of lane half h is pixel slot + 2 q + h (16 bytes = 4 floats)
+    int foA[4] = {0, 0, 0, 0};
+    auto set_span = [&](int m0) __attribute__((always_inline)) {
+        const SpanGeo g = span_geo(m0);
+        const int R = wm * 32 + (lane & 31);
+        const int slot = R < g.n0 ? 2 * R : g.c0 + 2 * (R - g.n0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) foA[q] = (slot + 2 * q + (lane >> 5)) * 4;
+    };
     struct Frag {
         f32x4 a[4], b[4];
     };
     Frag F0, F1;
     f32x16 acc;
     auto rall = [&](int stg, Frag& F) __attribute__((always_inline)) {
-        const float* Ab = smem + stg * STAGE + kg * SUB + (wm * 32) * 32;
+        const float* Ab = smem + stg * STAGE + kg * SUB + (SPAN ? 0 : (wm * 32) * 32);
         const float* Bb = smem + stg * STAGE + kg * SUB + (BM + wn * 32) * 32;
 #pragma unroll
-        for (int q = 0; q < 4; q++) F.a[q] = *(const f32x4*)(Ab + fo[q]), F.b[q] = *(const f32x4*)(Bb + fo[q]);
+        for (int q = 0; q < 4; q++) F.a[q] = *(const f32x4*)(Ab + (SPAN ? foA[q] : fo[q])), F.b[q] = *(const f32x4*)(Bb + fo[q]);
     };
     auto mma = [&](const f32x4& af, const f32x4& bf) __attribute__((always_inline)) {
         if constexpr (BF) {
@@ -546,7 +596,26 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             cbw += (unsigned)__builtin_amdgcn_s_memtime() - b0;
         } else
             __builtin_amdgcn_s_barrier();  // chunk g+1 visible; every consumer is past chunk g-1
-        if constexpr (!BF) {
+        if constexpr (SPAN) {
+            // 12 MFMAs per chunk (e = 3 is the zero padding channel); the next chunk's 8 fragment reads behind MFMAs 2, 3 of each group
+            const float* Ab = smem + nstage * STAGE;
+            const float* Bb = smem + nstage * STAGE + (BM + wn * 32) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], cur.b[q][e], acc, 0, 0, 0);
+                    if (e == 1) {
+                        nxt.a[q] = *(const f32x4*)(Ab + foA[q]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    } else if (e == 2) {
+                        nxt.b[q] = *(const f32x4*)(Bb + fo[q]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+        } else if constexpr (!BF) {
             const float* Ab = smem + nstage * STAGE + kg * SUB + (wm * 32) * 32;
             const float* Bb = smem + nstage * STAGE + kg * SUB + (BM + wn * 32) * 32;
 #pragma unroll
@@ -595,9 +664,19 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     }
     __builtin_amdgcn_s_barrier();  // chunk 0 visible
     if (pstamp) prof[11] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (SPAN) set_span(decode(0).m0);
     rall(0, F0);
     for (int j = 0; j < my_n; j++) {
         const Item it = decode(j);
+        if constexpr (SPAN) {
+            if (j > 0) {  // the A fragments prefetched behind the previous tile's last chunk used that tile's run geometry: read them
+                          // again (the stage is not retired before this wave has passed two more chunk barriers)
+                set_span(it.m0);
+                const float* Ab = smem + stage * STAGE;
+#pragma unroll
+                for (int q = 0; q < 4; q++) F0.a[q] = *(const f32x4*)(Ab + foA[q]);
+            }
+        }
         const int n = it.n0 + wn * 32 + col;
         const int mb = it.m0 + wm * 32 + rhalf;
         // bias and shortcut of this tile: requested now so the epilogue never waits for them.  (Straight-line code
@@ -872,6 +951,17 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
         }
     }
     if (a.bone) return hipErrorInvalidValue;
+    if constexpr (BM == 64 && BN == 64 && KG == 1) {
+        // conv1, fp32: the span form (VNECT_NO_SPAN=1: the gathered-window form, for A/B runs)
+        const bool no_span = getenv("VNECT_NO_SPAN") != nullptr;  // read per launch: a test flips it inside one process
+        if (a.pixmode && !a.bf16 && !no_span && a.ksplit == 1 && a.cpt == 1 && a.Wo >= 64 && a.stride == 2) {
+#define LAUNCH_SPAN(PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, false, PR, 0, true>), grid, dim3(512), lds, st, a)
+            if (prof == 0) LAUNCH_SPAN(0);
+            else LAUNCH_SPAN(1);
+#undef LAUNCH_SPAN
+            return hipGetLastError();
+        }
+    }
     if (a.bf16) {
         if (prof == 0) LAUNCH_STREAM(true, 0);
         else if (prof == 1) LAUNCH_STREAM(true, 1);
@@ -895,6 +985,7 @@ static hipError_t setup_stream()
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 1>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 1>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 0, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 0, true>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 2>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 2>);
     }
