@@ -86,7 +86,10 @@ template <typename V>
 __device__ __forceinline__ void store_wt(V* p, V v)
 {
     static_assert(sizeof(V) == 16 || sizeof(V) == 8, "one dwordx4 / dwordx2 store");
-    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // (the s_nop: gfx9 requires wait states between a VMEM store of more than 64 bits and a VALU write of its data registers;
+    // the compiler inserts them for its own stores but cannot see inside an asm block -- a thread that went on computing
+    // right behind such a store stored the next iteration's loop counter instead of its data: found in round 2)
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
     else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 #else

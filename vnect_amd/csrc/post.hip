@@ -372,7 +372,7 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_sys(f32x4g* p, f32x4g v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");  // system scope, write-through
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");  // system scope, write-through (s_nop: kernels.h, store_wt)
 #else
     *p = v;
 #endif
