@@ -178,6 +178,10 @@ struct JointsOut {
     int status;
 };
 
+// merge + arg-max + joints in ONE launch: the last of the 168 arg-max workgroups (agent-scope ticket, zero between launches) runs the
+// joints stage
+hipError_t launch_post(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, unsigned* ticket,
+                       FilterBank* fb, const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st);
 // multi-scale merge of the heat-maps (in LDS, the rows each workgroup needs) + arg-max of the virtual x8 upsample
 hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st);
 // out may be (device-mapped) pinned HOST memory: the kernel's 21x2 + 21x3 results then need no device-to-host copy

@@ -157,10 +157,8 @@ constexpr int ARG_THREADS = 384;  // one thread per column (368 used)
 constexpr int ARG_SEGS = 6;       // 8-row segments per workgroup: 8 slabs x 6 >= 47 segments, 168 workgroups keep the f64 work off one CU
 
 template <int SMAX>
-__global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* __restrict__ maps,
-                                                                  const MergeTabs* __restrict__ mtabs, int S,
-                                                                  const UpTab* __restrict__ up,
-                                                                  ArgPartial* __restrict__ part)
+__device__ __forceinline__ void argmax_body(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S,
+                                            const UpTab* __restrict__ up, ArgPartial* __restrict__ part)
 {
     __shared__ double map[HM * HM];
     __shared__ double sv[ARG_THREADS];
@@ -217,9 +215,19 @@ __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* _
         __syncthreads();
     }
     if (tid == 0) {
-        part[j * ARG_SLABS + slab].v = sv[0];
-        part[j * ARG_SLABS + slab].idx = si[0];
+        // write-through (agent scope): post_kernel's last workgroup reads all 168 partials behind an agent-scope ticket
+        ArgPartial* q = part + j * ARG_SLABS + slab;
+        __hip_atomic_store(&q->v, sv[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->idx, si[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+template <int SMAX>
+__global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* __restrict__ maps,
+                                                                  const MergeTabs* __restrict__ mtabs, int S,
+                                                                  const UpTab* __restrict__ up,
+                                                                  ArgPartial* __restrict__ part)
+{
+    argmax_body<SMAX>(maps, mtabs, S, up, part);
 }
 hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st)
 {
@@ -312,10 +320,10 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
 // estimator.py:132-139 for all 21 joints in one workgroup, one thread per filter: 42 2-D filters, then 63 read-offs
 // (x/y/z maps merged on demand) + root subtraction + 63 3-D filters, then the un-mapping.
 template <int SMAX>
-__global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
-                                                     const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
-                                                     const FrameParams* __restrict__ fp, const FrameDyn dyn, int nep50,
-                                                     JointsOut* __restrict__ out)
+__device__ __forceinline__ void joints_body(const ArgPartial* part, const float* __restrict__ maps,
+                                            const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
+                                            const FrameParams* __restrict__ fp, const FrameDyn& dyn, int nep50,
+                                            JointsOut* __restrict__ out)
 {
     __shared__ double c2[NJ * 2];
     __shared__ float p3[NJ * 3];
@@ -333,7 +341,10 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
     double pv[ARG_SLABS];
     int pi[ARG_SLABS];
 #pragma unroll
-    for (int s = 0; s < ARG_SLABS; s++) pv[s] = part[j2 * ARG_SLABS + s].v, pi[s] = part[j2 * ARG_SLABS + s].idx;
+    for (int s = 0; s < ARG_SLABS; s++) {  // `sc1` loads: in post_kernel the partials were written by other workgroups of this launch
+        pv[s] = __hip_atomic_load(&part[j2 * ARG_SLABS + s].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pi[s] = __hip_atomic_load(&part[j2 * ARG_SLABS + s].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (t < NJ * 2) {
         double bv = pv[0];
         int bi = pi[0];
@@ -355,6 +366,44 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
     }
     if (t < NJ * 2) out->j2d[t] = (c2[t] - off) / scaler;
     if (t == 0) out->status = 0;
+}
+template <int SMAX>
+__global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
+                                                     const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
+                                                     const FrameParams* __restrict__ fp, const FrameDyn dyn, int nep50,
+                                                     JointsOut* __restrict__ out)
+{
+    joints_body<SMAX>(part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+}
+
+// Both in ONE launch (round 2): the 168 arg-max workgroups publish their partials write-through and take an agent-scope ticket; the
+// workgroup whose ticket comes last -- every partial is then in memory -- runs the joints stage (filters, read-off, un-mapping) with
+// its first 105 threads.  Nobody waits: the other workgroups are gone by then.  The hand-off is the measured-valid form of
+// MI355X_MICROARCH.md (sc1 stores, s_waitcnt vmcnt(0), agent-scope add; the last arriver loads with sc1 after its add returned).
+template <int SMAX>
+__global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S,
+                                                           const UpTab* __restrict__ up, ArgPartial* part, unsigned* ticket,
+                                                           FilterBank* fb, const FrameParams* __restrict__ fp, const FrameDyn dyn,
+                                                           int nep50, JointsOut* __restrict__ out)
+{
+    argmax_body<SMAX>(maps, mtabs, S, up, part);
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's partial has left (write-through)
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = old == gridDim.x * gridDim.y - 1;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next frame
+    }
+    __syncthreads();
+    if (!last) return;
+    joints_body<SMAX>(part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+}
+hipError_t launch_post(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, unsigned* ticket,
+                       FilterBank* fb, const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
+{
+    if (S <= 3) hipLaunchKernelGGL(post_kernel<3>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part, ticket, fb, fp, dyn, nep50, out);
+    else hipLaunchKernelGGL(post_kernel<VNECT_MAX_S>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part, ticket, fb, fp, dyn, nep50, out);
+    return hipGetLastError();
 }
 hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
                          const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)

@@ -99,6 +99,8 @@ struct vnect_handle {
     MergeTabs* d_mtabs = nullptr;
     UpTab* d_up = nullptr;
     ArgPartial* d_part = nullptr;
+    unsigned* d_ticket = nullptr;  // post_kernel's arrival counter (zero between launches)
+    bool post_merged = true;       // merge + arg-max + joints as ONE launch (post_kernel); false: two launches (VNECT_NO_POST_MERGE=1)
     FilterBank* d_fb = nullptr;
     double* h_filt = nullptr;      // pinned, device-mapped: vnect_joint_filter's values in ([0, 64)) and out ([64, 128))
     double* h_filt_dev = nullptr;
@@ -1036,6 +1038,14 @@ int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
     return VNECT_OK;
 }
 
+// both in one launch (post.hip: post_kernel): takes the frame's arguments by value, so it runs behind the graph, not inside it
+int run_post(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
+{
+    const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
+    HIPCK(h, launch_post(maps, h->d_mtabs, h->S, h->d_up, h->d_part, h->d_ticket, h->d_fb, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
+    return VNECT_OK;
+}
+
 // OneEuroFilter.py:65-66: `if self.__lasttime and timestamp: self.__freq = 1.0 / (timestamp - self.__lasttime)`.
 //   t == last  -> ZeroDivisionError (VNECT_E_TIMESTAMP);
 //   t <  last  -> freq < 0, so alpha = 1 / (1 + tau * freq) leaves (0, 1] and LowPassFilter.__setAlpha raises ValueError
@@ -1167,7 +1177,7 @@ int run_frame_kernels(vnect_handle* h, bool timed)
     const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
     int rc = run_network(h, timed);
     if (rc) return rc;
-    if (!h->sharded && (rc = run_argmax(h))) return rc;
+    if (!h->sharded && !h->post_merged && (rc = run_argmax(h))) return rc;
     if (timed) {
         HIPCK(h, hipMemcpyAsync(h->h_prof, h->d_prof, pbytes, hipMemcpyDeviceToHost, h->st));
         HIPCK(h, hipMemcpyAsync(h->h_prof_end, h->d_prof_end, h->layers.size() * PROF_WGS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
@@ -1230,6 +1240,9 @@ int build_twin(vnect_handle* h)
     int rc;
     if ((rc = dev_alloc(t, &t->d_fp, 1))) return fail(h, rc, t->err);
     if ((rc = dev_alloc(t, &t->d_part, (size_t)NJ * ARG_SLABS))) return fail(h, rc, t->err);
+    if ((rc = dev_alloc(t, &t->d_ticket, 4))) return fail(h, rc, t->err);
+    HIPCK(h, hipMemset(t->d_ticket, 0, 4 * sizeof(unsigned)));
+    t->post_merged = h->post_merged;
     for (int i = 0; i < RING; i++) HIPCK(h, hipHostMalloc((void**)&t->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
     t->tensors = h->tensors, t->layers = h->layers, t->tensor_by_name = h->tensor_by_name;
     t->t_input4 = h->t_input4, t->t_out = h->t_out;
@@ -1310,12 +1323,13 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     if (L->sharded) {  // the one exchange of the pyramid path, then the merge + arg-max over everybody's maps
         if (g_roctx.pop) g_roctx.pop(), g_roctx.push("vnect:exchange+merge+argmax");
         if ((rc = exchange_maps(L, h->seq_submit))) return fail(h, rc, L->err);
-        if ((rc = run_argmax(L))) return fail(h, rc, L->err);
+        if (!L->post_merged && (rc = run_argmax(L))) return fail(h, rc, L->err);
     }
-    if (g_roctx.pop) g_roctx.pop(), g_roctx.push("vnect:filters+readoff");  // r_net's pop now closes this range
+    if (g_roctx.pop) g_roctx.pop(), g_roctx.push(L->post_merged ? "vnect:merge+argmax+filters+readoff" : "vnect:filters+readoff");  // r_net's pop now closes this range
     if (h->seq_submit > 0 && h->last_lane && h->last_lane != L)  // the filters are a chain: frame k's state feeds frame k+1
         HIPCK(h, hipStreamWaitEvent(L->st, h->done[(h->seq_submit - 1) % RING], 0));
-    if ((rc = run_joints(L, dyn, h->h_out_dev[ring]))) return fail(h, rc, L->err);  // writes the ring slot in pinned host memory
+    // writes the ring slot in pinned host memory
+    if ((rc = L->post_merged ? run_post(L, dyn, h->h_out_dev[ring]) : run_joints(L, dyn, h->h_out_dev[ring]))) return fail(h, rc, L->err);
     if (timed) HIPCK(h, hipEventRecord(h->ev[3], L->st));
     HIPCK(h, hipEventRecord(h->done[ring], L->st));
     commit_time(h, t2d, t3d);  // only now: every launch of the frame has been accepted
@@ -1471,6 +1485,9 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
+        if ((rc = dev_alloc(h, &h->d_ticket, 4))) return rc;
+        HIPCK(h, hipMemset(h->d_ticket, 0, 4 * sizeof(unsigned)));
+        h->post_merged = getenv("VNECT_NO_POST_MERGE") == nullptr;
         if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
         if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
         if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
@@ -1687,8 +1704,12 @@ int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d
         FrameDyn dyn{};
         dyn.t2d = t2d, dyn.t3d = t3d;
         if ((rc = sync_geometry(h, fp))) return rc;
-        if ((rc = run_argmax(h))) return rc;
-        if ((rc = run_joints(h, dyn, h->h_out_dev[0]))) return rc;
+        if (h->post_merged) {
+            if ((rc = run_post(h, dyn, h->h_out_dev[0]))) return rc;
+        } else {
+            if ((rc = run_argmax(h))) return rc;
+            if ((rc = run_joints(h, dyn, h->h_out_dev[0]))) return rc;
+        }
         commit_time(h, t2d, t3d);
         HIPCK(h, hipStreamSynchronize(h->st));
         memcpy(j2, h->h_out[0]->j2d, sizeof(double) * NJ * 2);
