@@ -99,6 +99,8 @@ def test_timestamp_errors_mirror_reference(weights):
         a(f[1], timestamp=9.5)
     with pytest.raises(ValueError):
         a.joint_filter(np.zeros((21, 2)), dim=2, timestamp=9.0)
+    with pytest.raises(TypeError):   # in place or not at all: a list cannot be filtered in place (nor indexed [i, 0] by the reference)
+        a.joint_filter([[0.0, 0.0]] * 21, dim=2, timestamp=11.0)
     with pytest.raises(ValueError):
         a.postprocess(helpers.synth_maps(1, 1), timestamp=(9.0, 11.0))
     x2, x3 = a(f[1], timestamp=10.04)

@@ -99,7 +99,9 @@ class VNectEstimator:
         ``numpy_promotion=``), any other dtype in float64 like ``joints_2d``.  ``timestamp=`` is additive (default: one
         ``time.time()`` per call, like the reference)."""
         t = time.time() if timestamp is None else float(timestamp)
-        a = joints if isinstance(joints, np.ndarray) else np.asarray(joints)
+        if not isinstance(joints, np.ndarray):  # the reference indexes joints[i, 0]: anything but an array fails there too
+            raise TypeError("joints must be a numpy array (it is filtered in place)")
+        a = joints
         if a.ndim != 2 or a.shape[0] < self.joints_sum or a.shape[1] < dim:
             raise IndexError("joints must hold at least (%d, %d) values" % (self.joints_sum, dim))
         dim = 2 if dim == 2 else 3  # the reference's `else` branch takes every other value as 3
