@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of 368x368, 3-scale VNect inference on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: one rank per GPU.  Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE) this process IS a rank; started bare
+(`python bench.py --gpus N`, no WORLD_SIZE) it spawns its N rank processes itself -- children with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, started BEFORE this process touches the GPU; it relays rank 0's JSON line and exits with the
+children's worst return code (never an exec of a process that has initialised HIP).
 
 A step is one pass of the hot path (VNectEstimator.__call__, /root/reference/src/estimator.py:97-142) over one
 synthetic 368x368 BGR frame at scales [1.0, 0.8, 0.6], fp32 (BASELINE.json configs[1]).  Frames are resident in
@@ -64,8 +69,7 @@ def cpu_framework_baseline(weights, budget_s):
     import torch
     import oracle
     from tests import helpers, torch_net
-    threads = min(16, len(os.sched_getaffinity(0)))
-    torch.set_num_threads(threads)
+    ncores = len(os.sched_getaffinity(0))
     est = oracle.OracleEstimator(weights=weights, scales=SCALES)
     frames = [helpers.synth_frame(1234 + k) for k in range(4)]
 
@@ -75,17 +79,32 @@ def cpu_framework_baseline(weights, budget_s):
             maps = torch_net.forward(weights, batch, dtype=torch.float32).numpy()
         return est.postprocess(maps, t, t, scaler, off[0], off[1])
 
-    frame(0, 1.0)
+    # the best this host can do, not an assumed cap: a short sweep over the intra-op thread count (2 frames each after one
+    # warm-up frame), then the sample on the fastest
+    sweep, clk = {}, 1.0
+    for th in sorted({t for t in (8, 16, 32, 64, 128, ncores) if t <= ncores}):
+        torch.set_num_threads(th)
+        clk += 1
+        frame(0, clk)
+        t0 = time.perf_counter()
+        for k in range(2):
+            clk += 1
+            frame(k, clk)
+        sweep[th] = round(2 / (time.perf_counter() - t0), 2)
+    threads = max(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    frame(0, clk + 1)
     n, t0 = 0, time.perf_counter()
     while True:
-        frame(n, 2.0 + n / 30)
+        frame(n, clk + 2 + n / 30)
         n += 1
         dt = time.perf_counter() - t0
         if (dt >= budget_s and n >= 3) or n >= 400:
             break
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "proxy: torch-CPU (oneDNN) fp32 network + oracle pre/post",
-            "sample": "%d frames of the same workload in %.1f s on %d threads of %d host cores (torch %s)"
-                      % (n, dt, threads, len(os.sched_getaffinity(0)), torch.__version__)}
+            "thread_sweep_frames_per_s": sweep,
+            "sample": "%d frames of the same workload in %.1f s on %d threads of %d host cores (torch %s; fastest of the sweep %s)"
+                      % (n, dt, threads, ncores, torch.__version__, sweep)}
 
 
 def committed(pattern, key):
@@ -155,6 +174,54 @@ def profile(run, h, n):
     return tim
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent has not imported torch
+    or loaded the HIP library, and never does), relay rank 0's JSON line, exit with the worst child return code.  A child that
+    fails takes the others down after a grace period (they would wait in a barrier for ever).  VNECT_BENCH_WORKER names another
+    worker script (the CPU test's stub)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    worker = os.environ.get("VNECT_BENCH_WORKER") or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VNECT_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, worker] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    limit = float(os.environ.get("VNECT_BENCH_SPAWN_TIMEOUT", "1500"))
+    t0, first_fail, out0 = time.time(), None, []
+    import threading
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_fail is None:
+            first_fail = time.time()
+        if (first_fail is not None and time.time() - first_fail > 15) or time.time() - t0 > limit:
+            for p in procs:          # the exact PIDs this function started
+                if p.poll() is None:
+                    p.kill()
+            break
+    rcs = [p.wait() for p in procs]
+    rd.join(timeout=10)
+    line = None
+    for ln in out0:
+        if ln.lstrip().startswith("{"):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    if line:
+        print(line, flush=True)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst == 0 and not line:
+        worst = 1
+    sys.exit(min(worst, 255))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,13 +241,18 @@ def main():
                          "frame; default for N>1 is N independent streams (configs[4])")
     ap.add_argument("--exchange", choices=["rccl", "p2p"], default="rccl",
                     help="--pyramid: ncclAllGather over RCCL, or direct peer writes over xGMI (SURVEY 8e asks for both)")
+    ap.add_argument("--pyramid-both", action="store_true",
+                    help="--pyramid with BOTH exchange forms in one job (rccl first, then p2p): the side-by-side SURVEY 8e asks for "
+                         "from one 3-GPU lease; `value` is the RCCL all-gather form (the one north_star names), p2p under \"pyramid_p2p\"")
     args = ap.parse_args()
 
+    if args.pyramid_both:
+        args.pyramid = True
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world  # the launcher's word counts
 
     import numpy as np
     import torch
@@ -198,6 +270,14 @@ def main():
     grp = Group(backend)
     rank = grp.rank
     local_rank = int(dev_override) if dev_override is not None else grp.local_rank
+    # what the run actually exercised: the world size as a real all-reduce over the backend sees it (backend "nccl" IS RCCL on
+    # ROCm), and where every rank sits
+    ranks_seen = grp.count_ranks()
+    try:
+        pci = torch.cuda.get_device_properties(local_rank).pci_bus_id
+    except Exception:
+        pci = None
+    placement = grp.all_gather_object({"rank": rank, "device": local_rank, "pci_bus_id": pci, "pid": os.getpid()})
     weights = synthetic_weights()
     nslots = 8
 
@@ -213,8 +293,14 @@ def main():
     if args.pyramid:
         if args.gpus != len(SCALES):
             sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
-        xc = _native.XCHG_P2P if args.exchange == "p2p" else _native.XCHG_RCCL
-        job = PyramidJob(grp, SCALES, lambda r, w, ex: make(args.precision, pyramid=(r, w), exchange=xc), args.exchange)
+        if args.pyramid_both:
+            args.exchange = "rccl"   # first leg; the p2p leg follows the headline's timed region and profile
+
+        def make_job(exchange):
+            xc = _native.XCHG_P2P if exchange == "p2p" else _native.XCHG_RCCL
+            return PyramidJob(grp, SCALES, lambda r, w, ex: make(args.precision, pyramid=(r, w), exchange=xc), exchange)
+
+        job = make_job(args.exchange)
         h = job.handle
     else:
         # lanes=3: the extra lanes only ever run frames submitted while others are in flight (the pipelined leg below)
@@ -314,6 +400,17 @@ def main():
     tim = None
     if rank == 0 or args.pyramid:  # pyramid: every inference contains the exchange, so every rank must take part
         tim = profile(lambda n: run(h, n), h, nprof)
+    pyramid_p2p = None
+    if args.pyramid_both:  # the same job again with the exchange by peer writes: same frames, steps, barriers; every rank takes part
+        h.close()
+        job = make_job("p2p")
+        h = job.handle
+        for k in range(nslots):
+            h.upload_frame(k, host_frames[k])
+        e2, lat2 = timed(h, args.steps, args.warmup)
+        pyramid_p2p = {"value": round(args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
+                       "exchange": "peer writes over xGMI (exchange_kernel)",
+                       "latency_ms": {"p50": round(float(np.percentile(lat2, 50)), 4), "p95": round(float(np.percentile(lat2, 95)), 4)}}
     out = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -338,6 +435,13 @@ def main():
                                       if args.pyramid else "stream replicas"},
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p95": round(float(np.percentile(lat, 95)), 4),
                            "max": round(float(lat.max()), 4)},
+            # evidence of what ran: ranks counted by an all-reduce on the process-group backend, and every rank's device
+            "rccl_ranks": ranks_seen if backend == "nccl" else None, "backend": backend, "backend_ranks": ranks_seen,
+            "ranks": placement, "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("VNECT_BENCH_SPAWNED") else
+                                               ("launcher (RANK / WORLD_SIZE in the environment)" if args.gpus > 1 else "single process"),
+            "exchange": (("rccl: ncclAllGather of 710 976 B per rank" if args.exchange == "rccl" else "p2p: peer writes over xGMI")
+                         if args.pyramid else None),
+            "pyramid_p2p": pyramid_p2p,
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),

@@ -797,3 +797,65 @@ def test_bf16_path_gated_against_fp32(weights, oracle_net, h3):
         assert np.all(d3[same] <= bound3)
     assert float(np.abs(mb - mf).max()) <= 3e-2 * float(np.abs(mf).max())
     hb.close()
+
+
+def _round_bf16(a):
+    """float32 -> nearest-even bfloat16 -> float32 (what the bf16 path's per-layer rounding does to a value)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def test_bf16_benchmarked_plan_parity(weights, oracle_net, h3):
+    """The bf16 plan bench.py times is the ARENA plan (tail GEMM + bone fusion on, S = 3), not the private-buffer one the
+    per-layer gate reads back.  (1) its maps equal the private-buffer handle's bit for bit (the fp32 twin of this check is in
+    test_conv_stack_every_layer) and sit within 3e-2 of the oracle; (2) over 4 frames incl. non-square ones, for EVERY joint the
+    fp32 heat-map at the bf16 arg-max is within 2 eps of its maximum, and the arena handle's joints equal the private-buffer
+    handle's; (3) where the heat-maps have a real maximum (planted peaks, utils.py:153-175 semantics) bf16-rounded maps give
+    21/21 joints within one heat-map cell."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
+    ref = oracle_net.forward(batch)
+    fused = _handle(BASELINE_SCALES, weights, precision=n.BF16)                              # what bench.py builds
+    plain = _handle(BASELINE_SCALES, weights, precision=n.BF16, keep_activations=True)       # what the per-layer gate reads
+    names = [L["name"] for L in fused.layers()]
+    assert any(">" in x for x in names) and any("bone_length" in x and "deconv" in x for x in names), names   # fused launches present
+    assert not any(">" in L["name"] for L in plain.layers())
+    mf, mp = fused.forward(batch), plain.forward(batch)
+    assert np.array_equal(mf, mp)                                                            # (1)
+    assert float(np.abs(mf - ref).max() / np.abs(ref).max()) <= 3e-2
+    worst_close = 21
+    for k, (H, W) in enumerate([(368, 368), (538, 368), (240, 320), (368, 368)]):           # (2)
+        frame = helpers.synth_frame(777 + k, H, W, smooth=True)
+        t = T0 + 500 + k / 30
+        j2a, j3a = fused.infer(frame, t, t + 0.001)
+        j2p, j3p = plain.infer(frame, t, t + 0.001)
+        assert np.array_equal(j2a, j2p) and np.array_equal(j3a, j3p), k
+        if k == 0:
+            h3.reset_filters()
+        j2f, j3f = h3.infer(frame, t, t + 0.001)
+        mb, m32 = fused.activation("res5c_branch2c"), h3.activation("res5c_branch2c")
+        top = float(np.abs(m32).max())
+        assert float(np.abs(mb - m32).max()) <= 3e-2 * top, k
+        eps = 3e-2 * top
+        avg_f = oracle.merge_scales(m32, BASELINE_SCALES)[0]
+        raw_b = oracle.extract_2d(oracle.merge_scales(mb, BASELINE_SCALES)[0])
+        for j in range(21):
+            up = oracle.resize(np.ascontiguousarray(avg_f[:, :, j]), 8.0)
+            assert up[int(raw_b[j, 0]), int(raw_b[j, 1])] >= up.max() - 2 * eps, (k, j)
+        if k == 0:  # first frame: the filters are the identity, so joints_2d ARE the arg-max positions
+            scaler = 368.0 / max(H, W)
+            worst_close = min(worst_close, int(np.all(np.abs(j2a - j2f) <= 8.0 / scaler + 1e-9, axis=1).sum()))
+    print("bf16 arena plan: worst frame has %d/21 joints within one cell of fp32 (noise heat-maps)" % worst_close)
+    assert worst_close >= 15
+    # (3) planted peaks: the post-processing of bf16-rounded maps against the fp32 maps
+    for seed in (5, 6, 7):
+        maps = helpers.synth_maps(seed, 3)
+        fused.reset_filters()
+        a2, a3 = fused.postprocess(_round_bf16(maps), T0, T0 + 0.001)
+        fused.reset_filters()
+        b2, b3 = fused.postprocess(maps, T0, T0 + 0.001)
+        assert np.all(np.abs(a2 - b2) <= 8.0), seed       # 21/21 within one heat-map cell (oracle on the same maps: 0, 1 and 7 px)
+    fused.close(), plain.close()

@@ -53,6 +53,15 @@ def test_joint_filter_in_place_bit_exact(weights, promo):
     j3b = (keep + np.float32(1.5)).astype(np.float32)
     est.joint_filter(j3b, dim=3, timestamp=T0 + 0.04)
     assert np.all(np.abs(j3b - keep) <= 1.5) and not np.array_equal(j3b, keep + np.float32(1.5))   # smoothed towards the past
+    # `dim` is normalised the way the reference's if / else reads it (estimator.py:85-93): anything but 2 is the 3-D bank, and a
+    # (21, 2) array then fails where the reference's joints[i, 2] does -- with IndexError, before any state changes
+    with pytest.raises(IndexError):
+        est.joint_filter(np.zeros((21, 2)), dim=1, timestamp=T0 + 1)
+    with pytest.raises(IndexError):
+        est.joint_filter(np.zeros((21, 2)), dim=3, timestamp=T0 + 1)
+    j3c = (keep + np.float32(3)).astype(np.float32)
+    assert est.joint_filter(j3c, dim=5, timestamp=T0 + 0.08) is j3c      # the 3-D bank again
+    assert not np.array_equal(j3c, keep + np.float32(3))
     est.close()
 
 

@@ -140,3 +140,50 @@ def test_three_rank_pyramid_host_logic_gloo(tmp_path):
         outs.append(eval(o.strip().splitlines()[-1]))
     assert {o["rank"] for o in outs} == {0, 1, 2}
     assert outs[0]["frames"] == outs[1]["frames"] == outs[2]["frames"]   # one stream, seen by all ranks
+
+
+SPAWN_STUB = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+from vnect_amd.parallel import Group
+assert os.environ["VNECT_BENCH_SPAWNED"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+g = Group("gloo")                      # the ranks the parent started rendezvous by themselves
+n = g.count_ranks()                    # a real all-reduce over the backend
+seen = g.all_gather_object({"rank": g.rank, "device": g.local_rank})
+if g.rank == 0:
+    print("rank 0 chatter that is not the result line", flush=True)
+    print(json.dumps({"n_gpus": g.world, "backend_ranks": n, "ranks": seen, "argv": sys.argv[1:]}), flush=True)
+else:
+    print("rank %%d must not reach the parent's stdout" %% g.rank, flush=True)
+g.close()
+sys.exit(int(os.environ.get("STUB_FAIL_RANK", "-1")) == g.rank and 7 or 0)
+"""
+
+
+def _run_bench_bare(tmp_path, extra_env, gpus=2):
+    stub = tmp_path / "stub_worker.py"
+    stub.write_text(SPAWN_STUB % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(VNECT_BENCH_WORKER=str(stub), **extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher (the driver's command shape): the parent starts 2 rank processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line -- and only that line -- and exits 0."""
+    import json
+    r = _run_bench_bare(tmp_path, {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["backend_ranks"] == 2
+    assert [(x["rank"], x["device"]) for x in out["ranks"]] == [(0, 0), (1, 1)]
+    assert out["argv"] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]   # the children get the parent's arguments
+    assert "rank 1 must not reach" in r.stderr and "rank 0 chatter" in r.stderr
+
+
+def test_bench_spawner_reports_the_worst_return_code(tmp_path):
+    r = _run_bench_bare(tmp_path, {"STUB_FAIL_RANK": "1"})
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])

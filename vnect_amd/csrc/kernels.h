@@ -127,6 +127,10 @@ struct FrameDyn {     // what does change every frame: passed to the two kernels
     double t2d, t3d;
     const uint8_t* frame;  // device pointer
     long long row_stride;
+    // pyramid-sharded handle, exchange by peer writes: device word that exchange_kernel sets to the frame's sequence number when a
+    // peer's maps did not arrive (nullptr otherwise); post_kernel then skips the joints stage of frame `xseq`
+    const unsigned* xfail;
+    unsigned xseq;
 };
 
 struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.img_scale_padding)
@@ -205,7 +209,8 @@ struct XchgArgs {
     char* block[8];          // every rank's exchange block as THIS device addresses it (block[rank] is the local one)
     float* gather;           // local (nranks, 46,46,84): what the merge / arg-max / joints kernels read
     unsigned* tickets;       // local, [8]: chunk-workgroups of a peer that have finished their stores
-    int* status;             // device-mapped pinned host word: set to 1 if a peer's flag did not arrive within the bound
+    int* status;             // device-mapped pinned host word (one per result-ring slot): set to 1 if a peer's flag did not arrive within the bound
+    unsigned* dfail;         // device word: set to `seq` in that case (what post_kernel tests, FrameDyn::xfail)
     int rank, nranks, parity;
     unsigned seq;            // frame sequence number (> 0), the flag value
     unsigned spin_limit;     // polls before giving up (each ~1 us)

@@ -156,16 +156,36 @@ __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { ret
 constexpr int ARG_THREADS = 384;  // one thread per column (368 used)
 constexpr int ARG_SEGS = 6;       // 8-row segments per workgroup: 8 slabs x 6 >= 47 segments, 168 workgroups keep the f64 work off one CU
 
+// (max value, lowest flat index) over the 64 lanes of a wave by butterfly exchanges (DPP / ds_bpermute under __shfl_xor): every lane
+// ends with the wave's winner.  `better` is a total order on (v, i) pairs with distinct i, so the result does not depend on the
+// exchange pattern.
+__device__ __forceinline__ void wave_argmax(double& v, int& i)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const double ov = __shfl_xor(v, m, 64);
+        const int oi = __shfl_xor(i, m, 64);
+        if (better(ov, oi, v, i)) v = ov, i = oi;
+    }
+}
+
+// `smt`: the merge tables in LDS (staged by the caller, visible after this function's first barrier).
 template <int SMAX>
-__device__ __forceinline__ void argmax_body(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S,
+__device__ __forceinline__ void argmax_body(const float* __restrict__ maps, const MergeTabs* smt, int S,
                                             const UpTab* __restrict__ up, ArgPartial* __restrict__ part)
 {
     __shared__ double map[HM * HM];
-    __shared__ double sv[ARG_THREADS];
-    __shared__ int si[ARG_THREADS];
+    __shared__ double wv[ARG_THREADS / 64];
+    __shared__ int wi[ARG_THREADS / 64];
     __shared__ double tb0[16], tb1[16];  // the 8 row phases (rows 4..11 of the table)
     const int j = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
     if (tid < 16) tb0[tid] = up->b0[tid], tb1[tid] = up->b1[tid];
+    // this thread's column of the x8 upsample: requested NOW, in flight behind the merge (none of it depends on the merge; left
+    // behind the barrier it was one more memory round trip on the kernel's critical path)
+    const int x = tid, xc = x < BOX ? x : BOX - 1;
+    const int sx = up->sx[xc], edge = up->edge[xc];
+    const double a0 = up->a0[xc], a1 = up->a1[xc];
+    __syncthreads();  // smt (and tb0 / tb1) visible
     {   // the multi-scale merge (estimator.py:105-129) of exactly the heat-map rows this slab blends: at most 7 of the 46,
         // one cell per thread -- no separate merge launch, no f64 plane in HBM
         const int g0 = slab * ARG_SEGS, g1 = g0 + ARG_SEGS < 47 ? g0 + ARG_SEGS : 47;
@@ -173,19 +193,16 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
         const int cells = (r_hi - r_lo + 1) * HM;
         for (int p = tid; p < cells; p += ARG_THREADS) {
             const int r = r_lo + p / HM, c = p % HM;
-            map[r * HM + c] = merged_cell<SMAX>(maps, mtabs, S, j, r, c);
+            map[r * HM + c] = merged_cell<SMAX>(maps, smt, S, j, r, c);
         }
     }
     __syncthreads();
     // Row structure of the x8 upsample (checked against the table on the host, build_up_table): destination row y
     // belongs to segment g = (y + 4) / 8 and phase p = (y + 4) % 8; it blends source rows max(g-1, 0) and min(g, 45)
     // with weights b0[4 + p], b1[4 + p].  Segment 0 has phases 4..7 (rows 0..3), segment 46 phases 0..3 (rows 364..367).
-    const int x = tid;
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
     if (x < BOX) {
-        const int sx = up->sx[x], edge = up->edge[x];
-        const double a0 = up->a0[x], a1 = up->a1[x];
         double w0[8], w1[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) w0[p] = tb0[4 + p], w1[p] = tb1[4 + p];
@@ -206,19 +223,18 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
             }
         }
     }
-    sv[tid] = bv, si[tid] = bi;
+    // wave reduction in registers, then ONE cross-wave step through LDS (was: a 9-barrier LDS tree)
+    wave_argmax(bv, bi);
+    if ((tid & 63) == 0) wv[tid >> 6] = bv, wi[tid >> 6] = bi;
     __syncthreads();
-    if (tid < 128 && better(sv[tid + 256], si[tid + 256], sv[tid], si[tid])) sv[tid] = sv[tid + 256], si[tid] = si[tid + 256];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s && better(sv[tid + s], si[tid + s], sv[tid], si[tid])) sv[tid] = sv[tid + s], si[tid] = si[tid + s];
-        __syncthreads();
-    }
     if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < ARG_THREADS / 64; w++)
+            if (better(wv[w], wi[w], bv, bi)) bv = wv[w], bi = wi[w];
         // write-through (agent scope): post_kernel's last workgroup reads all 168 partials behind an agent-scope ticket
         ArgPartial* q = part + j * ARG_SLABS + slab;
-        __hip_atomic_store(&q->v, sv[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&q->idx, si[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->v, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->idx, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 template <int SMAX>
@@ -227,7 +243,9 @@ __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* _
                                                                   const UpTab* __restrict__ up,
                                                                   ArgPartial* __restrict__ part)
 {
-    argmax_body<SMAX>(maps, mtabs, S, up, part);
+    __shared__ MergeTabs smt;
+    stage_merge_tabs(mtabs, &smt, S);
+    argmax_body<SMAX>(maps, &smt, S, up, part);
 }
 hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st)
 {
@@ -319,25 +337,20 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
 
 // estimator.py:132-139 for all 21 joints in one workgroup, one thread per filter: 42 2-D filters, then 63 read-offs
 // (x/y/z maps merged on demand) + root subtraction + 63 3-D filters, then the un-mapping.
+// `smt`: the merge tables in LDS, staged (and made visible by a barrier) by the caller.  `f2` / `f3`: this thread's filter states,
+// loaded by the caller -- in post_kernel at the very start of EVERY workgroup, so that the one that turns out to be last does not
+// start a memory round trip for them then.
 template <int SMAX>
-__device__ __forceinline__ void joints_body(const ArgPartial* part, const float* __restrict__ maps,
-                                            const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
-                                            const FrameParams* __restrict__ fp, const FrameDyn& dyn, int nep50,
-                                            JointsOut* __restrict__ out)
+__device__ __forceinline__ void joints_body(const ArgPartial* part, const float* __restrict__ maps, const MergeTabs* smt, int S,
+                                            FilterBank* fb, Filt& f2, Filt& f3, double scaler, double off, const FrameDyn& dyn,
+                                            int nep50, JointsOut* __restrict__ out)
 {
     __shared__ double c2[NJ * 2];
     __shared__ float p3[NJ * 3];
-    __shared__ MergeTabs smt;
     const int t = threadIdx.x;
-    // Every global read that does not depend on a computed value is requested up front (tables, partials, both
-    // filter states, frame parameters): the kernel is one workgroup and is priced in memory round trips.
-    stage_merge_tabs(mtabs, &smt, S);  // visible after the barrier below
     const int j2 = t < NJ * 2 ? t >> 1 : 0, k2 = t & 1;
     const int j3 = t < NJ * 3 ? t / 3 : 0, k3 = t < NJ * 3 ? t - 3 * j3 : 0;
-    Filt f2 = fb->f2[j2][k2];
-    Filt f3 = fb->f3[j3][k3];
-    const double t2d = dyn.t2d, t3d = dyn.t3d, scaler = fp->scaler;
-    const double off = k2 == 0 ? (double)fp->offy : (double)fp->offx;
+    const double t2d = dyn.t2d, t3d = dyn.t3d;
     double pv[ARG_SLABS];
     int pi[ARG_SLABS];
 #pragma unroll
@@ -357,7 +370,7 @@ __device__ __forceinline__ void joints_body(const ArgPartial* part, const float*
         fb->f2[j2][k2] = f2;
     }
     __syncthreads();
-    if (t < NJ * 3) p3[t] = (float)(pt_interp<SMAX>(maps, &smt, S, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
+    if (t < NJ * 3) p3[t] = (float)(pt_interp<SMAX>(maps, smt, S, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
     __syncthreads();
     if (t < NJ * 3) {
         const float v = p3[t] - p3[14 * 3 + k3];  // joints_3d -= joints_3d[14, :] in float32
@@ -367,36 +380,74 @@ __device__ __forceinline__ void joints_body(const ArgPartial* part, const float*
     if (t < NJ * 2) out->j2d[t] = (c2[t] - off) / scaler;
     if (t == 0) out->status = 0;
 }
+// this thread's filter states and un-mapping constants (threads past 63 hold copies of joint 0's: never written back)
+__device__ __forceinline__ void load_filters(const FilterBank* fb, const FrameParams* __restrict__ fp, Filt& f2, Filt& f3, double& scaler,
+                                             double& off)
+{
+    const int t = threadIdx.x;
+    const int j2 = t < NJ * 2 ? t >> 1 : 0, k2 = t & 1;
+    const int j3 = t < NJ * 3 ? t / 3 : 0, k3 = t < NJ * 3 ? t - 3 * j3 : 0;
+    f2 = fb->f2[j2][k2];
+    f3 = fb->f3[j3][k3];
+    scaler = fp->scaler;
+    off = k2 == 0 ? (double)fp->offy : (double)fp->offx;
+}
 template <int SMAX>
 __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
                                                      const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
                                                      const FrameParams* __restrict__ fp, const FrameDyn dyn, int nep50,
                                                      JointsOut* __restrict__ out)
 {
-    joints_body<SMAX>(part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+    __shared__ MergeTabs smt;
+    // Every global read that does not depend on a computed value is requested up front (tables, both filter states, frame
+    // parameters; the partials at the top of joints_body): the kernel is one workgroup and is priced in memory round trips.
+    stage_merge_tabs(mtabs, &smt, S);
+    Filt f2, f3;
+    double scaler, off;
+    load_filters(fb, fp, f2, f3, scaler, off);
+    __syncthreads();
+    joints_body<SMAX>(part, maps, &smt, S, fb, f2, f3, scaler, off, dyn, nep50, out);
 }
 
 // Both in ONE launch (round 2): the 168 arg-max workgroups publish their partials write-through and take an agent-scope ticket; the
 // workgroup whose ticket comes last -- every partial is then in memory -- runs the joints stage (filters, read-off, un-mapping) with
-// its first 105 threads.  Nobody waits: the other workgroups are gone by then.  The hand-off is the measured-valid form of
-// MI355X_MICROARCH.md (sc1 stores, s_waitcnt vmcnt(0), agent-scope add; the last arriver loads with sc1 after its add returned).
+// its first 105 threads.  Nobody waits: the other workgroups are gone by then.  The hand-off is, cell for cell, the first row of
+// MI355X_MICROARCH.md's table of hand-offs measured valid with `sc1` loads in place of an acquire: ONE lane per storing workgroup stores
+// its bytes `sc1` (8- and 4-byte), waits vmcnt(0), adds to ONE unsharded agent-scope counter; the workgroup whose add came last loads
+// (`sc1`, 8- and 4-byte) only after its add has returned, its other waves behind a workgroup barrier.  An explicit release / acquire
+// pair instead (buffer_wbl2 sc1 / buffer_inv sc1) is priced at ~1.7 us EACH in the same guide, on the critical path of a kernel
+// that is nothing but a chain of round trips -- so the relaxed form stays, and this comment is what keeps it honest: any change
+// to the store / wait / add / load sequence must be checked against that table again.
+// Round 3: every workgroup requests what the joints stage needs that does not depend on the arg-max (merge tables -> LDS, which the
+// merge itself uses; the first 105 threads' filter states and un-mapping constants -> registers) before anything else, so the last
+// arriver starts no memory round trip for them; on a pyramid-sharded handle a frame whose exchange failed (dyn.xfail) skips the
+// joints stage -- the filter banks do not advance on stale maps -- and reports status 1.
 template <int SMAX>
 __global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S,
                                                            const UpTab* __restrict__ up, ArgPartial* part, unsigned* ticket,
                                                            FilterBank* fb, const FrameParams* __restrict__ fp, const FrameDyn dyn,
                                                            int nep50, JointsOut* __restrict__ out)
 {
-    argmax_body<SMAX>(maps, mtabs, S, up, part);
+    __shared__ MergeTabs smt;
     __shared__ int last;
+    stage_merge_tabs(mtabs, &smt, S);
+    Filt f2, f3;
+    double scaler, off;
+    load_filters(fb, fp, f2, f3, scaler, off);
+    argmax_body<SMAX>(maps, &smt, S, up, part);
     if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's partial has left (write-through)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's `sc1` stores of the partial have left (write-through)
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = old == gridDim.x * gridDim.y - 1;
         if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next frame
     }
-    __syncthreads();
+    __syncthreads();  // the other waves of the last arriver load the partials (sc1) only behind this barrier
     if (!last) return;
-    joints_body<SMAX>(part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+    if (dyn.xfail && __hip_atomic_load(dyn.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == dyn.xseq) {
+        if (threadIdx.x == 0) out->status = 1;  // the exchange of THIS frame timed out: stale maps, leave the filters alone
+        return;
+    }
+    joints_body<SMAX>(part, maps, &smt, S, fb, f2, f3, scaler, off, dyn, nep50, out);
 }
 hipError_t launch_post(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, unsigned* ticket,
                        FilterBank* fb, const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
@@ -467,7 +518,10 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XchgArgs a)
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         ok = seen == a.seq;
-        if (!ok) *a.status = 1;
+        if (!ok) {
+            *a.status = 1;
+            __hip_atomic_store(a.dfail, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     if (!ok) return;

@@ -88,6 +88,7 @@ struct vnect_handle {
     vnect_handle* last_lane = nullptr;  // lane of the most recently submitted frame
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
+    size_t pre_frame_cap = 0;   // preprocess_only: bytes of the one, growable frame slot
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; long long last_use = -1; };  // last_use: sequence number of the last frame that reads this slot
     std::vector<SlotInfo> slots;
     FrameParams* d_fp = nullptr;   // crop geometry on the device; re-uploaded only when it differs from fp_dev
@@ -138,8 +139,9 @@ struct vnect_handle {
     bool xopened[VNECT_MAX_SCALES] = {};  // xpeer[r] came from hipIpcOpenMemHandle (close it on destroy)
     bool p2p_ready = false;
     unsigned* xtickets = nullptr;
-    int* h_xstatus = nullptr;          // pinned, device-mapped: a peer's flag did not arrive within the bound
+    int* h_xstatus = nullptr;          // pinned, device-mapped, one word per result-ring slot: a peer's flag did not arrive within the bound
     int* h_xstatus_dev = nullptr;
+    unsigned* d_xfail = nullptr;       // device word: sequence number of the last frame whose exchange failed (post_kernel skips its joints stage)
 };
 
 namespace {
@@ -1145,13 +1147,13 @@ bool load_rccl()
 
 // rank r's (46,46,84) maps -> slot r of the (S,46,46,84) gather buffer on every rank (the one exchange of SURVEY 8e),
 // by ncclAllGather or by peer writes (kernels.h: XchgArgs).  `seq` numbers the frame (the p2p flag value).
-int exchange_maps(vnect_handle* h, unsigned long long seq)
+int exchange_maps(vnect_handle* h, unsigned long long seq, int ring)
 {
     const Tensor& t = h->tensors[h->t_out];
     if (h->cfg.exchange == VNECT_XCHG_P2P) {
         if (!h->p2p_ready) return fail(h, VNECT_E_STATE, "pyramid-sharded handle (p2p): call vnect_comm_p2p_init before inference");
         XchgArgs a{};
-        a.src = t.d, a.gather = h->gather, a.tickets = h->xtickets, a.status = h->h_xstatus_dev;
+        a.src = t.d, a.gather = h->gather, a.tickets = h->xtickets, a.status = h->h_xstatus_dev + ring, a.dfail = h->d_xfail;
         for (int r = 0; r < h->S; r++) a.block[r] = h->xpeer[r];
         a.rank = h->cfg.pyramid_rank, a.nranks = h->S, a.parity = (int)(seq & 1), a.seq = (unsigned)(seq + 1);
         const char* lim = getenv("VNECT_XCHG_SPINS");  // polls (~1 us each) before a missing peer fails the frame; default ~2 s
@@ -1287,7 +1289,7 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     rc = check_time(h, t2d, t3d);
     if (rc) return rc;
     const int ring = (int)(h->seq_submit % RING);
-    FrameDyn dyn;
+    FrameDyn dyn{};
     dyn.t2d = t2d, dyn.t3d = t3d;
     dyn.row_stride = si.stride;
     dyn.frame = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
@@ -1322,7 +1324,8 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     }
     if (L->sharded) {  // the one exchange of the pyramid path, then the merge + arg-max over everybody's maps
         if (g_roctx.pop) g_roctx.pop(), g_roctx.push("vnect:exchange+merge+argmax");
-        if ((rc = exchange_maps(L, h->seq_submit))) return fail(h, rc, L->err);
+        if ((rc = exchange_maps(L, h->seq_submit, ring))) return fail(h, rc, L->err);
+        dyn.xfail = L->d_xfail, dyn.xseq = (unsigned)(h->seq_submit + 1);  // post_kernel skips the joints stage of a frame whose exchange failed
         if (!L->post_merged && (rc = run_argmax(L))) return fail(h, rc, L->err);
     }
     if (g_roctx.pop) g_roctx.pop(), g_roctx.push(L->post_merged ? "vnect:merge+argmax+filters+readoff" : "vnect:filters+readoff");  // r_net's pop now closes this range
@@ -1352,9 +1355,12 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
     if (q == hipErrorNotReady) q = hipEventSynchronize(h->done[ring]);
     HIPCK(h, q);
     h->seq_collect++;
-    if (h->h_xstatus && *h->h_xstatus) {
-        *h->h_xstatus = 0;
-        return fail(h, VNECT_E_COMM, "pyramid exchange: a peer's maps did not arrive within the bound (ranks out of step?)");
+    if (h->h_xstatus && h->h_xstatus[ring]) {  // one word per ring slot: the error lands on the frame it belongs to
+        h->h_xstatus[ring] = 0;
+        // The frame's joints stage was skipped on the device (post_kernel: the filter banks did not advance on stale maps), but the
+        // ranks are out of step now and the host's timestamps have moved: VNECT_E_COMM means tear the job down and reconnect.
+        return fail(h, VNECT_E_COMM, "pyramid exchange: a peer's maps did not arrive within the bound (ranks out of step?); "
+                                     "destroy the handles of every rank and reconnect");
     }
     if (j2) memcpy(j2, h->h_out[ring]->j2d, sizeof(double) * NJ * 2);
     if (j3) memcpy(j3, h->h_out[ring]->j3d, sizeof(float) * NJ * 3);
@@ -1419,6 +1425,17 @@ int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int 
     if (!bgr || slot < 0 || slot >= (int)h->slots.size()) return fail(h, VNECT_E_ARG, "bad frame slot");
     if (H < 1 || W < 1 || row_stride < (int64_t)W * 3) return fail(h, VNECT_E_ARG, "bad frame geometry");
     if ((size_t)H * W * 3 > (size_t)h->cfg.max_frame_bytes) return fail(h, VNECT_E_ARG, "frame larger than max_frame_bytes");
+    if (h->pre_only && (size_t)H * W * 3 > h->pre_frame_cap) {  // the one slot of a pre-processing-only handle grows with its frames
+        HIPCK(h, hipStreamSynchronize(h->st));
+        if (h->frames) {
+            HIPCK(h, hipFree(h->frames));
+            h->dev_allocs.erase(std::find(h->dev_allocs.begin(), h->dev_allocs.end(), (void*)h->frames));
+            h->frames = nullptr, h->pre_frame_cap = 0;
+        }
+        int rc = dev_alloc(h, &h->frames, (size_t)H * W * 3);
+        if (rc) return rc;
+        h->pre_frame_cap = (size_t)H * W * 3;
+    }
     uint8_t* dst = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
     // a frame still being read by an in-flight inference must not be overwritten: wait for that inference only (frames in
     // other slots keep running, so a pipelined caller uploads frame k+1 while frames k and k-1 compute)
@@ -1471,15 +1488,21 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         h->bf16 = cfg->precision == VNECT_BF16;
         h->sharded = sharded;
         h->keep_activations = cfg->keep_activations != 0;
+        const bool pre = cfg->preprocess_only != 0;
+        h->pre_only = pre;
         if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
         if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
+        // gen_input_batch alone (the static method creates and destroys such a handle per call): ONE frame slot that grows with the
+        // frames it is given (upload_frame_impl), no gather buffer, no filter bank, no profiling buffers -- the resize tables and the
+        // (S,368,368) batch + its read-back staging are all it owns (~20 MB at S = 3)
+        if (pre) h->cfg.num_frame_slots = 1;
         *out = h;  // returned even on failure below so the caller can read the message, then destroy
         HIPCK(h, hipSetDevice(cfg->device));
         HIPCK(h, hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
         HIPCK(h, conv_setup());
         h->slots.resize(h->cfg.num_frame_slots);
         int rc;
-        if ((rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
+        if (!pre && (rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
         if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
@@ -1488,9 +1511,9 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         if ((rc = dev_alloc(h, &h->d_ticket, 4))) return rc;
         HIPCK(h, hipMemset(h->d_ticket, 0, 4 * sizeof(unsigned)));
         h->post_merged = getenv("VNECT_NO_POST_MERGE") == nullptr;
-        if ((rc = dev_alloc(h, &h->d_fb, 1))) return rc;
-        if ((rc = dev_alloc(h, &h->in3, (size_t)VNECT_MAX_SCALES * BOX * BOX * 3))) return rc;
-        if ((rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
+        if (!pre && (rc = dev_alloc(h, &h->d_fb, 1))) return rc;
+        if ((rc = dev_alloc(h, &h->in3, (size_t)(pre ? h->Snet : VNECT_MAX_SCALES) * BOX * BOX * 3))) return rc;
+        if (!pre && (rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
         for (int i = 0; i < RING; i++) {
             HIPCK(h, hipHostMalloc((void**)&h->h_fp[i], sizeof(FrameParams), hipHostMallocDefault));
             HIPCK(h, hipHostMalloc((void**)&h->h_out[i], sizeof(JointsOut), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1499,40 +1522,47 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         }
         if (sharded && cfg->exchange == VNECT_XCHG_P2P) {
             // fine-grained device memory: peers' stores and the system-scope loads of this device bypass its L2, so a slot is
-            // never served from a line cached two frames ago
+            // never served from a line cached two frames ago.  The protocol DEPENDS on it (exchange_kernel polls flags and reads slots
+            // that a peer writes over xGMI): no silent fall-back to coarse-grained memory, whose stale flags / slots would
+            // time out or -- worse -- merge old maps.
             void* q = nullptr;
             hipError_t e = hipExtMallocWithFlags(&q, XCHG_BYTES, hipDeviceMallocFinegrained);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
-                HIPCK(h, hipMalloc(&q, XCHG_BYTES));
+                return fail(h, VNECT_E_COMM, std::string("exchange = VNECT_XCHG_P2P needs fine-grained device memory "
+                                                         "(hipExtMallocWithFlags(hipDeviceMallocFinegrained): ") +
+                                                 hipGetErrorString(e) + "); use VNECT_XCHG_RCCL");
             }
             h->dev_allocs.push_back(q);
             h->xblock = (char*)q;
             HIPCK(h, hipMemset(h->xblock, 0, XCHG_BYTES));
             if ((rc = dev_alloc(h, &h->xtickets, 8))) return rc;
             HIPCK(h, hipMemset(h->xtickets, 0, 8 * sizeof(unsigned)));
-            HIPCK(h, hipHostMalloc((void**)&h->h_xstatus, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-            *h->h_xstatus = 0;
+            HIPCK(h, hipHostMalloc((void**)&h->h_xstatus, RING * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+            for (int i = 0; i < RING; i++) h->h_xstatus[i] = 0;
+            if ((rc = dev_alloc(h, &h->d_xfail, 4))) return rc;
+            HIPCK(h, hipMemset(h->d_xfail, 0, 4 * sizeof(unsigned)));
             HIPCK(h, hipHostGetDevicePointer((void**)&h->h_xstatus_dev, h->h_xstatus, 0));
             h->xpeer[cfg->pyramid_rank] = h->xblock;
         }
         HIPCK(h, hipHostMalloc((void**)&h->h_filt, 128 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         HIPCK(h, hipHostGetDevicePointer((void**)&h->h_filt_dev, h->h_filt, 0));
         for (auto& e : h->ev) HIPCK(h, hipEventCreate(&e));
-        if ((rc = dev_alloc(h, &h->d_prof, PROF_SLOTS * 128))) return rc;
-        if ((rc = dev_alloc(h, &h->d_prof_end, (size_t)PROF_WGS * 128))) return rc;
-        HIPCK(h, hipMemset(h->d_prof_end, 0, (size_t)PROF_WGS * 128 * sizeof(unsigned long long)));
-        HIPCK(h, hipHostMalloc((void**)&h->h_prof_end, (size_t)PROF_WGS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
-        HIPCK(h, hipHostMalloc((void**)&h->h_prof, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
-        for (int i = 0; i < PROF_SLOTS * 128; i++) h->h_prof[i] = 0;
+        if (!pre) {
+            if ((rc = dev_alloc(h, &h->d_prof, PROF_SLOTS * 128))) return rc;
+            if ((rc = dev_alloc(h, &h->d_prof_end, (size_t)PROF_WGS * 128))) return rc;
+            HIPCK(h, hipMemset(h->d_prof_end, 0, (size_t)PROF_WGS * 128 * sizeof(unsigned long long)));
+            HIPCK(h, hipHostMalloc((void**)&h->h_prof_end, (size_t)PROF_WGS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
+            HIPCK(h, hipHostMalloc((void**)&h->h_prof, PROF_SLOTS * 128 * sizeof(unsigned long long), hipHostMallocDefault));
+            for (int i = 0; i < PROF_SLOTS * 128; i++) h->h_prof[i] = 0;
+        }
         if ((rc = build_scale_tables(h))) return rc;
         if ((rc = build_up_table(h))) return rc;
-        if ((rc = reset_filters_impl(h))) return rc;
+        if (!pre && (rc = reset_filters_impl(h))) return rc;
         h->tim.struct_size = sizeof(vnect_timings);
-        if (cfg->preprocess_only) {
+        if (pre) {
             // gen_input_batch alone (the reference's static method needs no session either, estimator.py:70-81): the input
             // batch buffer and the tables made above; no weights, no launch plan, vnect_finalize is refused
-            h->pre_only = true;
             h->t_input4 = add_tensor(h, "input", h->Snet, BOX, BOX, 3, 4);
             Tensor& t = h->tensors[h->t_input4];
             char* p = nullptr;
@@ -1777,6 +1807,7 @@ int vnect_joint_filter(vnect_handle* h, int dim, const double* joints_in, int va
 {
     return guarded(&h, [&]() -> int {
         if (!h || !joints_in || !joints_out || (dim != 2 && dim != 3)) return h ? fail(h, VNECT_E_ARG, "vnect_joint_filter: bad argument") : VNECT_E_ARG;
+        if (h->pre_only) return fail(h, VNECT_E_STATE, "vnect_joint_filter on a preprocess_only handle (it has no filter bank)");
         if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
         HIPCK(h, hipSetDevice(h->cfg.device));
         // the timestamp rules of check_time, for the one bank this call advances
@@ -1802,6 +1833,7 @@ int vnect_reset_filters(vnect_handle* h)
     return guarded(&h, [&]() -> int {
         if (!h) return VNECT_E_ARG;
         if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        if (h->pre_only) return fail(h, VNECT_E_STATE, "vnect_reset_filters on a preprocess_only handle (it has no filter bank)");
         HIPCK(h, hipSetDevice(h->cfg.device));
         return reset_filters_impl(h);
     });

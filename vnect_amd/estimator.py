@@ -102,9 +102,9 @@ class VNectEstimator:
         if not isinstance(joints, np.ndarray):  # the reference indexes joints[i, 0]: anything but an array fails there too
             raise TypeError("joints must be a numpy array (it is filtered in place)")
         a = joints
-        if a.ndim != 2 or a.shape[0] < self.joints_sum or a.shape[1] < dim:
+        dim = 2 if dim == 2 else 3  # the reference's `else` branch takes every other value as 3 (dim=1, dim=5, ... included)
+        if a.ndim != 2 or a.shape[0] < self.joints_sum or a.shape[1] < dim:  # where the reference's joints[i, 2] raises
             raise IndexError("joints must hold at least (%d, %d) values" % (self.joints_sum, dim))
-        dim = 2 if dim == 2 else 3  # the reference's `else` branch takes every other value as 3
         try:
             out = self._h.joint_filter(dim, a[:self.joints_sum, :dim], a.dtype == np.float32, t)
         except _native.VnectError as e:

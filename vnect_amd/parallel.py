@@ -40,6 +40,17 @@ class Group:
         if self._dist:
             self._dist.barrier()
 
+    def count_ranks(self):
+        """The world size as the backend itself sees it: SUM of 1 over all ranks through a real all-reduce (on the GPUs with
+        "nccl" == RCCL).  bench.py reports it, so an N > 1 line says what its collective actually spanned."""
+        if not self._dist:
+            return 1
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.ones(1, dtype=torch.int32, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return int(t.item())
+
     def max_over_ranks(self, value):
         """MAX of a Python float over all ranks (every rank gets the result)."""
         if not self._dist:
