@@ -120,6 +120,56 @@ def test_conv1_span_form_is_bit_identical(weights, oracle_net, monkeypatch):
         assert float(np.abs(out - r).max()) <= 1e-4 * float(np.abs(r).max())
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_stem_is_bit_identical(weights, monkeypatch, prec):
+    """The stem as ONE launch (stem.hip: [gen_input_batch ->] conv1 + ReLU -> max-pool on spatial tiles, vnect_model.py:27-29,
+    estimator.py:70-81) against the three stand-alone kernels: pool1 -- read from handles with private buffers, VNECT_FORCE_STEM puts
+    the fused form on such a handle -- the final maps and the joints must be EQUAL, for both patch sources (the batch tensor; the
+    uint8 frame), S = 1, 3 and 4 (row groups of 4 and of 5 pooled rows; more tiles than CUs), square and non-square frames, and
+    through vnect_forward's (S,368,368,3) entry."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    p = n.BF16 if prec == "bf16" else n.FP32
+    frames = [helpers.synth_frame(31, smooth=True), helpers.synth_frame(32, 538, 368, smooth=True), helpers.synth_frame(33, 240, 320)]
+    for scales in (BASELINE_SCALES, [1.0], [1, 0.85, 0.7, 0.5]):
+        plain = _handle(scales, weights, precision=p, keep_activations=True)
+        assert [L["name"] for L in plain.layers()][:2] == ["conv1", "pool1"]
+        batch, _, _ = oracle.gen_input_batch(frames[1], scales)
+        want_fwd = plain.forward(batch)
+        want_pool_fwd = plain.activation("pool1")
+        want = []
+        for k, f in enumerate(frames):
+            t = T0 + 900 + k / 30
+            j2, j3 = plain.infer(f, t, t + 0.001)
+            want.append((j2, j3, plain.activation("pool1"), plain.activation("res5c_branch2c")))
+        plain.close()
+        for mode in ("batch", "frame"):
+            monkeypatch.setenv("VNECT_FORCE_STEM", mode)
+            fused = _handle(scales, weights, precision=p, keep_activations=True)
+            monkeypatch.delenv("VNECT_FORCE_STEM")
+            assert np.array_equal(fused.forward(batch), want_fwd), (scales, mode)          # vnect_forward: the stem reads the batch
+            assert np.array_equal(fused.activation("pool1"), want_pool_fwd), (scales, mode)
+            for k, f in enumerate(frames):
+                t = T0 + 900 + k / 30
+                j2, j3 = fused.infer(f, t, t + 0.001)
+                assert np.array_equal(fused.activation("pool1"), want[k][2]), (scales, mode, k)
+                assert np.array_equal(fused.activation("res5c_branch2c"), want[k][3]), (scales, mode, k)
+                assert np.array_equal(j2, want[k][0]) and np.array_equal(j3, want[k][1]), (scales, mode, k)
+            fused.close()
+    # the product default: arena handles run the stem from the frame; VNECT_NO_STEM restores the three launches
+    a = _handle(BASELINE_SCALES, weights, precision=p)
+    monkeypatch.setenv("VNECT_NO_STEM", "1")
+    b = _handle(BASELINE_SCALES, weights, precision=p)
+    monkeypatch.delenv("VNECT_NO_STEM")
+    for k, f in enumerate(frames):
+        t = T0 + 950 + k / 30
+        ra, rb = a.infer(f, t, t + 0.001), b.infer(f, t, t + 0.001)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]), k
+        assert np.array_equal(a.activation("res5c_branch2c"), b.activation("res5c_branch2c")), k
+    a.close(), b.close()
+
+
 def test_conv_stack_batch_independent(h3, oracle_net):
     """The S images are independent: permuting the batch permutes the output (what sharding relies on)."""
     import oracle
@@ -156,6 +206,7 @@ def test_every_tile_shape_on_every_layer(weights, oracle_net, monkeypatch, force
     batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77, smooth=True), scales)
     ref = oracle_net.forward(batch)
     monkeypatch.setenv("VNECT_FORCE_TILE", force)
+    monkeypatch.setenv("VNECT_NO_STEM", "1")   # conv1 as a launch of its own (the fused stem has ONE shape; its parity test is below)
     h = _handle(scales, weights, precision=_native().BF16 if prec == "bf16" else _native().FP32)
     shapes = {(L["tile_m"], L["tile_n"], L["split_k"]) for L in h.layers() if L["M"]}
     out = h.forward(batch)

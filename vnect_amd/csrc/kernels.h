@@ -143,6 +143,28 @@ struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.
 
 hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
+// ---- the stem as one launch (stem.hip): [gen_input_batch ->] conv1 + ReLU -> 3x3 / stride-2 max-pool on spatial tiles -------------
+constexpr int STEM_TW = 23;          // pooled columns per tile (92 = 4 x 23)
+constexpr int STEM_MAXH = 5;         // pooled rows per tile at most
+constexpr int STEM_MAXGROUPS = 92;   // row groups per image at most
+struct StemArgs {
+    const void* batch;     // (S,368,368,4) NHWC4 batch (fp32 / bf16), or nullptr with from_frame
+    const FrameParams* fp; // from_frame: the three arguments of pyramid_kernel
+    FrameDyn dyn;
+    const ScaleTabs* tabs;
+    const float* w;        // conv1's packed weights as the stand-alone layer has them: fp32 [64][7 rows][8 px][4 ch], bf16 [64][4 row pairs][2][8][4]
+    const float* bias;     // [64]
+    void* out;             // pool1 (S,92,92,64), fp32 / bf16
+    unsigned long long* prof;      // profiling twin: start stamp (workgroup 0) ...
+    unsigned long long* prof_end;  // ... and every workgroup's end stamp, like ConvArgs
+    int S, groups;         // images; row groups per image (grid = S * groups * 4 tiles)
+    int scale_base;        // from_frame: image 0 of the batch is scale `scale_base` (a pyramid-sharded rank)
+    int bf16, from_frame;
+    unsigned char row0[STEM_MAXGROUPS + 1];  // first pooled row of every group; row0[groups] = 92
+};
+hipError_t launch_stem(const StemArgs& a, hipStream_t st);
+hipError_t stem_setup();  // one-time function attributes (dynamic LDS size)
+
 // ---- post-processing ------------------------------------------------------------------
 struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale
     int copy;

@@ -70,6 +70,11 @@ struct vnect_handle {
     std::vector<Layer> layers;
     std::map<std::string, int> tensor_by_name;
     int t_input4 = -1, t_out = -1;
+    // The stem as one launch (stem.hip): conv1 + pool1 [+ gen_input_batch].  0: off (the stand-alone layers), 1: from the batch
+    // tensor (behind pyramid_kernel; also what vnect_forward uses), 2: from the frame (no pyramid launch, no batch tensor).
+    int stem_mode = 0;
+    int l_conv1 = -1, l_pool1 = -1;  // the two layers a stem launch stands for
+    StemArgs stem{};
     float* in3 = nullptr;  // (S,368,368,3) staging for vnect_forward / preprocess read-back
     float* ws = nullptr;
     size_t ws_floats = 0;
@@ -666,6 +671,40 @@ void bind_activations(vnect_handle* h, Layer& L)
     L.r.ws = h->ws, L.r.resid = a.resid, L.r.out = a.out;
 }
 
+// The fused stem (stem.hip) stands for layers l_conv1 + l_pool1 (and, from the frame, for pyramid_kernel).  Default: from the frame
+// on handles whose layers share the arena; handles with per-layer read-back keep the stand-alone layers (their "conv1" activation
+// must exist) unless VNECT_FORCE_STEM says otherwise (the parity test reads pool1 from both forms).  VNECT_NO_STEM=1 restores the
+// three launches, VNECT_STEM=batch keeps pyramid_kernel and fuses conv1 + pool1 only (A/B runs).
+void setup_stem(vnect_handle* h)
+{
+    h->stem_mode = 0;
+    if (h->l_conv1 < 0 || h->l_pool1 != h->l_conv1 + 1) return;
+    const Layer& C = h->layers[h->l_conv1];
+    const Tensor& tin = h->tensors[h->t_input4];
+    const Tensor& tp = h->tensors[h->layers[h->l_pool1].out];
+    if (tin.H != BOX || tin.W != BOX || tp.H != 92 || tp.W != 92 || tp.Cs != 64 || C.a.Npad != 64 || C.a.ksplit != 1) return;
+    const char* force = getenv("VNECT_FORCE_STEM");
+    const char* mode = getenv("VNECT_STEM");
+    if (getenv("VNECT_NO_STEM")) return;
+    if (h->keep_activations && !force) return;
+    if (force) mode = force;
+    h->stem_mode = (mode && !strcmp(mode, "batch")) ? 1 : 2;
+    StemArgs& a = h->stem;
+    memset(&a, 0, sizeof a);
+    a.batch = tin.d, a.w = C.w, a.bias = C.bias, a.out = tp.d;
+    a.fp = h->d_fp, a.tabs = h->d_stabs;
+    a.S = h->Snet, a.scale_base = h->sharded ? h->cfg.pyramid_rank : 0, a.bf16 = h->bf16;
+    // row groups of 4 and 5 pooled rows: as few tiles as one round over the 256 CUs allows (S = 3: 21 groups -> 252 tiles),
+    // never more than 5 rows per tile (the LDS patch), never fewer than 4 (the halo rows are recomputed per tile)
+    int G = 256 / (4 * a.S);
+    G = G < 19 ? 19 : (G > 23 ? 23 : G);
+    a.groups = G;
+    const int base = 92 / G, rem = 92 % G;
+    int r = 0;
+    for (int g = 0; g < G; g++) a.row0[g] = (unsigned char)r, r += base + (g < rem ? 1 : 0);
+    a.row0[G] = (unsigned char)r;
+}
+
 int finalize_impl(vnect_handle* h)
 {
     const int S = h->Snet;
@@ -693,7 +732,9 @@ int finalize_impl(vnect_handle* h)
         Layer L;
         L.op = OP_POOL, L.name = "pool1", L.in = conv1;
         pool1 = L.out = add_tensor(h, "pool1", S, ho, wo, 64, 64);
+        h->l_conv1 = (int)h->layers.size() - 1;
         h->layers.push_back(L);
+        h->l_pool1 = (int)h->layers.size() - 1;
     }
     // bottleneck blocks (vnect_model.py:31-165); block output tensors are named resNx
     auto proj = [&](const std::string& p, int x, int mid, int out, int stride) {
@@ -981,13 +1022,26 @@ int finalize_impl(vnect_handle* h)
         h->conv_flops += L.flops;
         h->conv_launches += 1;
     }
+    setup_stem(h);
     return VNECT_OK;
 }
 
 // ---- launch sequences -------------------------------------------------------------------------------
-int run_network(vnect_handle* h, bool timed)
+// `stem_done`: the caller has launched the stem from the frame already (enqueue_frame: it takes the frame's arguments by value)
+int run_network(vnect_handle* h, bool timed, bool stem_done = false)
 {
     for (Layer& L : h->layers) {
+        const int li = (int)(&L - h->layers.data());
+        if (h->stem_mode && (li == h->l_conv1 || li == h->l_pool1)) {
+            if (li == h->l_conv1 && !stem_done) {  // from the batch tensor (stem_mode 1, or vnect_forward on a stem_mode 2 handle)
+                StemArgs a = h->stem;
+                a.from_frame = 0;
+                a.prof = timed ? h->d_prof + PROF_SLOTS * li : nullptr;
+                a.prof_end = timed ? h->d_prof_end + (size_t)PROF_WGS * li : nullptr;
+                HIPCK(h, launch_stem(a, h->st));
+            }
+            continue;
+        }
         if (L.op == OP_CONV) {
             ConvArgs a = L.a;
             a.prof = timed ? h->d_prof + PROF_SLOTS * (&L - h->layers.data()) : nullptr;
@@ -1017,8 +1071,16 @@ int sync_geometry(vnect_handle* h, const FrameParams& fp)
     return VNECT_OK;
 }
 
-int run_pre(vnect_handle* h, const FrameDyn& dyn)
+int run_pre(vnect_handle* h, const FrameDyn& dyn, bool timed = false, bool want_batch = false)
 {
+    if (h->stem_mode == 2 && !want_batch) {  // gen_input_batch + conv1 + pool1 in one launch: the batch tensor is never written
+        StemArgs a = h->stem;
+        a.from_frame = 1, a.dyn = dyn;
+        a.prof = timed ? h->d_prof + PROF_SLOTS * h->l_conv1 : nullptr;
+        a.prof_end = timed ? h->d_prof_end + (size_t)PROF_WGS * h->l_conv1 : nullptr;
+        HIPCK(h, launch_stem(a, h->st));
+        return VNECT_OK;
+    }
     HIPCK(h, launch_pyramid(h->d_fp, dyn, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
                             h->sharded ? h->cfg.pyramid_rank : 0, h->bf16, h->st));
     return VNECT_OK;
@@ -1177,7 +1239,7 @@ bool comm_ready(const vnect_handle* h) { return h->cfg.exchange == VNECT_XCHG_P2
 int run_frame_kernels(vnect_handle* h, bool timed)
 {
     const size_t pbytes = h->layers.size() * PROF_SLOTS * sizeof(unsigned long long);
-    int rc = run_network(h, timed);
+    int rc = run_network(h, timed, h->stem_mode == 2);  // stem_mode 2: run_pre has launched the stem in front of this
     if (rc) return rc;
     if (!h->sharded && !h->post_merged && (rc = run_argmax(h))) return rc;
     if (timed) {
@@ -1256,6 +1318,8 @@ int build_twin(vnect_handle* h)
     if (t->ws_floats && (rc = dev_alloc(t, &t->ws, t->ws_floats))) return fail(h, rc, t->err);
     for (Layer& L : t->layers)
         if (L.op == OP_CONV) bind_activations(t, L);
+    t->l_conv1 = h->l_conv1, t->l_pool1 = h->l_pool1;
+    setup_stem(t);  // same plan as lane 0, this lane's arena and geometry block
     t->finalized = true;
     if ((rc = build_graph(t))) return fail(h, rc, t->err);
     HIPCK(h, hipStreamSynchronize(t->st));
@@ -1307,7 +1371,7 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     if (timed) HIPCK(h, hipEventRecord(h->ev[0], L->st));
     {
         RoctxRange r("vnect:gen_input_batch");
-        if ((rc = run_pre(L, dyn))) return fail(h, rc, L->err);
+        if ((rc = run_pre(L, dyn, timed))) return fail(h, rc, L->err);
     }
     RoctxRange r_net("vnect:conv_stack+merge+argmax");
     // use_graph 2 (auto): a frame submitted while nothing is in flight -- the synchronous pattern -- is launched eagerly (median
@@ -1397,7 +1461,9 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
             for (int k = 1; k <= 8; k++) e = std::max(e, h->h_prof[PROF_SLOTS * i + k]);
             return e;
         };
-        auto direct = [&](size_t a, size_t b) { return b == a + 1 && h->layers[a].a.ksplit == 1; };  // no kernel in between
+        auto direct = [&](size_t a, size_t b) {  // no kernel in between (the stem stands for conv1 AND pool1)
+            return (b == a + 1 || (h->stem_mode && (int)a == h->l_conv1 && b == a + 2)) && h->layers[a].a.ksplit == 1;
+        };
         for (size_t c = 0; c + 1 < convs.size(); c++)
             if (direct(convs[c], convs[c + 1]) && t_start(convs[c + 1]) > t_end(convs[c]))
                 gaps.push_back((double)(t_start(convs[c + 1]) - t_end(convs[c])) * 1e-5);
@@ -1500,6 +1566,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         HIPCK(h, hipSetDevice(cfg->device));
         HIPCK(h, hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
         HIPCK(h, conv_setup());
+        HIPCK(h, stem_setup());
         h->slots.resize(h->cfg.num_frame_slots);
         int rc;
         if (!pre && (rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
@@ -1701,7 +1768,7 @@ int vnect_preprocess(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t 
         FrameDyn dyn{};
         dyn.row_stride = h->slots[0].stride, dyn.frame = h->frames;
         if ((rc = sync_geometry(h, fp))) return rc;
-        if ((rc = run_pre(h, dyn))) return rc;
+        if ((rc = run_pre(h, dyn, false, true))) return rc;
         if (batch_out) {
             const long long npix = (long long)h->Snet * BOX * BOX;
             HIPCK(h, launch_strip4to3(h->tensors[h->t_input4].d, h->in3, npix, h->bf16, h->st));
