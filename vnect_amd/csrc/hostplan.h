@@ -1,0 +1,375 @@
+// hostplan.h -- the pure-host planning logic of libvnect_hip.so: OpenCV-compatible resize tables, the merge / upsample tables of the
+// post-processing, weight packing into the kernels' layouts (incl. the transposed conv's four sub-pixel phases), the activation
+// arena's first-fit placement, the per-layer tile choice, and the fused stem's row groups.  Header-only and HIP-free on purpose:
+// runtime.cpp uses it for the product, and `make hostplan_asan` builds the same code with g++ -fsanitize=address,undefined behind a
+// small C shim (hostplan_capi.cpp) that tests/test_hostplan.py drives on the CPU box -- the ~2 000 lines of runtime.cpp otherwise
+// only ever run next to a GPU.
+//
+// Reference arithmetic: cv2.resize(INTER_LINEAR) as used by /root/reference/src/utils.py:13-21 (via :107-150) and
+// src/estimator.py:112-119, src/utils.py:169-171; TF layouts of src/vnect_model.py:27-217.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tables.h"
+
+namespace vnect {
+namespace plan {
+
+// ---- OpenCV INTER_LINEAR table builders (resize.cpp semantics) ----------------------
+inline int cv_round(double v) { return (int)nearbyint(v); }  // round half to even
+inline int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+inline int16_t sat_short(float v)
+{
+    int r = (int)nearbyintf(v);
+    return (int16_t)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+struct AxisTab {
+    std::vector<int> s0, s1, edge;
+    std::vector<float> f;
+    int xmax = 0;
+};
+// x axis: offset clamped and fraction zeroed at both borders; columns >= xmax use the single tap
+inline AxisTab axis_x(int ssize, int dsize, double scale)
+{
+    AxisTab t;
+    t.s0.resize(dsize), t.s1.resize(dsize), t.edge.resize(dsize), t.f.resize(dsize);
+    t.xmax = dsize;
+    for (int d = 0; d < dsize; d++) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) fx = 0, sx = 0;
+        if (sx + 1 >= ssize) {
+            t.xmax = std::min(t.xmax, d);
+            if (sx >= ssize - 1) fx = 0, sx = ssize - 1;
+        }
+        t.s0[d] = sx, t.s1[d] = std::min(sx + 1, ssize - 1), t.f[d] = fx;
+    }
+    for (int d = 0; d < dsize; d++) t.edge[d] = d >= t.xmax;
+    return t;
+}
+// y axis: floor + fraction kept; the two source rows are clipped into the image
+inline AxisTab axis_y(int ssize, int dsize, double scale)
+{
+    AxisTab t;
+    t.s0.resize(dsize), t.s1.resize(dsize), t.edge.assign(dsize, 0), t.f.resize(dsize);
+    for (int d = 0; d < dsize; d++) {
+        float fy = (float)((d + 0.5) * scale - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        t.s0[d] = clipi(sy, 0, ssize), t.s1[d] = clipi(sy + 1, 0, ssize), t.f[d] = fy;
+    }
+    return t;
+}
+
+// cv2.resize(u8 src (sh,sw), (0,0), fx=fy=f): destination size and fixed-point tables
+inline bool build_u8_tab(int sh, int sw, double f, ResizeTab* t)
+{
+    memset(t, 0, sizeof *t);
+    if (!(f > 0.0) || sh < 1 || sw < 1) return false;
+    const double dwf = sw * f, dhf = sh * f;
+    if (!(dwf < 1e6) || !(dhf < 1e6)) return false;  // before the casts below: a hostile factor must not overflow an int
+    t->dw = cv_round(dwf), t->dh = cv_round(dhf);
+    if (t->dw < 1 || t->dh < 1 || t->dw > BOX || t->dh > BOX) return false;
+    t->copy = (t->dw == sw && t->dh == sh);
+    const double scale = 1.0 / f;
+    AxisTab x = axis_x(sw, t->dw, scale), y = axis_y(sh, t->dh, scale);
+    t->xmax = x.xmax;
+    for (int d = 0; d < t->dw; d++) {
+        t->sx[d] = (int16_t)x.s0[d];
+        t->a0[d] = sat_short((1.f - x.f[d]) * 2048.f);
+        t->a1[d] = sat_short(x.f[d] * 2048.f);
+    }
+    for (int d = 0; d < t->dh; d++) {
+        t->sy0[d] = (int16_t)y.s0[d], t->sy1[d] = (int16_t)y.s1[d];
+        t->b0[d] = sat_short((1.f - y.f[d]) * 2048.f);
+        t->b1[d] = sat_short(y.f[d] * 2048.f);
+    }
+    return true;
+}
+
+// One 8-bit bilinear sample through a ResizeTab, exactly as the device code (pyramid.h: sample_u8x3) evaluates it -- the host twin the
+// CPU tests compare with the oracle's resize; `px(row, col)` yields a source value.
+template <typename Px>
+inline int sample_u8(Px px, const ResizeTab& t, int dy, int dx)
+{
+    if (t.copy) return px(dy, dx);
+    const int r0y = t.sy0[dy], r1y = t.sy1[dy], sx = t.sx[dx];
+    int r0, r1;
+    if (dx < t.xmax) {
+        r0 = px(r0y, sx) * t.a0[dx] + px(r0y, sx + 1) * t.a1[dx];
+        r1 = px(r1y, sx) * t.a0[dx] + px(r1y, sx + 1) * t.a1[dx];
+    } else {
+        r0 = px(r0y, sx) * 2048, r1 = px(r1y, sx) * 2048;
+    }
+    return (((t.b0[dy] * (r0 >> 4)) >> 16) + ((t.b1[dy] * (r1 >> 4)) >> 16) + 2) >> 2;
+}
+
+// (float)v / 255 - 0.4 in float32: `batch / 255.0 - 0.4` of estimator.py:79-80
+inline void fill_lut(float* lut)
+{
+    for (int v = 0; v < 256; v++) lut[v] = (float)v / 255.f - 0.4f;
+}
+
+// pyramid entry i of the ScaleTabs (utils.img_scale_padding, estimator.py:77: `... if scale < 1 else img_square`).
+// Returns nullptr on success, else the reason.
+inline const char* build_scale_tab(double s, ScaleTabs* st, int i)
+{
+    if (!(s > 0.0) || s > 1.0) return "scales must be in (0, 1]";
+    st->scaled[i] = s < 1.0;
+    st->pad[i] = 0;
+    if (st->scaled[i]) {
+        if (!build_u8_tab(BOX, BOX, s, &st->t[i])) return "scale too small";
+        st->pad[i] = (BOX - st->t[i].dh) / 2;  // utils.py:137-140; the remainder pads the far side
+    }
+    return nullptr;
+}
+
+// estimator.py:112-119: rescale = 1.0 / scale; cv2.resize(map, fx=fy=rescale); centre crop 46x46
+inline const char* build_merge_tab(double s, MergeTab* m)
+{
+    if (!(s > 0.0) || s > 1.0) return "scales must be in (0, 1]";
+    const double f = 1.0 / s;
+    if (!(HM * f < 1e6)) return "scale too small";
+    const int ds = cv_round(HM * f);
+    if (ds < HM) return "scale > 1 not supported";
+    memset(m, 0, sizeof *m);
+    m->copy = ds == HM;
+    const double scale = 1.0 / f;
+    AxisTab x = axis_x(HM, ds, scale), y = axis_y(HM, ds, scale);
+    const int off = ds / 2 - HM / 2;
+    for (int r = 0; r < HM; r++) {
+        const int d = r + off;
+        m->sx[r] = x.s0[d], m->edge[r] = x.edge[d];
+        m->a0[r] = 1.f - x.f[d], m->a1[r] = x.f[d];
+        m->sy0[r] = y.s0[d], m->sy1[r] = y.s1[d];
+        m->b0[r] = 1.f - y.f[d], m->b1[r] = y.f[d];
+    }
+    return nullptr;
+}
+
+// utils.py:169-171: cv2.resize(hm (46,46) f64, fx=fy=8) -> 368x368.  Returns false if the table does not have the (segment, phase)
+// row structure heat_argmax_kernel relies on.
+inline bool build_up_tab(UpTab* u)
+{
+    AxisTab x = axis_x(HM, BOX, 1.0 / 8.0), y = axis_y(HM, BOX, 1.0 / 8.0);
+    for (int d = 0; d < BOX; d++) {
+        u->sx[d] = x.s0[d], u->edge[d] = x.edge[d];
+        u->a0[d] = (double)(1.f - x.f[d]), u->a1[d] = (double)x.f[d];
+        u->sy0[d] = y.s0[d], u->sy1[d] = y.s1[d];
+        u->b0[d] = (double)(1.f - y.f[d]), u->b1[d] = (double)y.f[d];
+    }
+    for (int d = 0; d < BOX; d++) {
+        const int g = (d + 4) / 8, ph = (d + 4) % 8;
+        if (u->sy0[d] != std::max(g - 1, 0) || u->sy1[d] != std::min(g, HM - 1) || u->b0[d] != u->b0[4 + ph] || u->b1[d] != u->b1[4 + ph])
+            return false;
+    }
+    return true;
+}
+
+// utils.img_scale_squarify + img_padding geometry for an (H,W) frame.  nullptr on success, else the reason.
+inline const char* squarify(int H, int W, FrameParams* c)
+{
+    if (H < 1 || W < 1 || H > 8192 || W > 8192) return "frame size out of range";
+    memset(c, 0, sizeof *c);
+    c->scaler = (double)BOX / std::max(H, W);
+    if (!build_u8_tab(H, W, c->scaler, &c->sq)) return "squarify: scaled size exceeds 368";
+    const int h2 = c->sq.dh, w2 = c->sq.dw;
+    // utils.py:98-103 indexes a 368-long axis with the scaled long side; numpy raises if it is not 368
+    if ((h2 > w2 ? h2 : w2) != BOX) return "squarify: scaled long side != 368";
+    if (h2 > w2) c->offx = BOX / 2 - w2 / 2;
+    else c->offy = BOX / 2 - h2 / 2;
+    c->H = H, c->W = W;
+    return nullptr;
+}
+
+// ---- number formats ------------------------------------------------------------------------------
+// fp32 -> bf16, round to nearest even (weights are finite)
+inline uint16_t to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline float from_bf16(uint16_t b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+inline void same_pad(int in, int k, int stride, int* out, int* before)
+{
+    *out = (in + stride - 1) / stride;
+    int tot = std::max((*out - 1) * stride + k - in, 0);
+    *before = tot / 2;
+}
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- weight packing: TF layouts -> the GEMM B operand [Npad][K], K contiguous ------------------------
+// k index of filter element (ky, kx, ci) of a tc.layers.conv2d kernel (kh,kw,Cin,Cout):
+//   ordinary layers: (ky * k + kx) * cp + ci, cp = the input tensor's pixel stride (channels padded to whole K chunks);
+//   conv1 (7x7 on the NHWC4 input): fp32 ky * 32 + kx * 4 + ci (7 chunks of 8 pixels x 4 channels, pixel 7 / channel 3 zero),
+//                                   bf16 (ky >> 1) * 64 + (ky & 1) * 32 + kx * 4 + ci (4 chunks of 2 rows, row 7 zero too).
+inline size_t conv_kidx(int k, int ky, int kx, int ci, int cp, bool conv1, bool bf16)
+{
+    if (conv1) return bf16 ? (size_t)(ky >> 1) * 64 + (ky & 1) * 32 + kx * 4 + ci : (size_t)ky * 32 + kx * 4 + ci;
+    return (size_t)(ky * k + kx) * cp + ci;
+}
+// W (k,k,cin,cout) -> wp [Npad][K] starting at row n0 (a paired launch concatenates two layers along N)
+inline void pack_conv(const float* W, int k, int cin, int cout, int cp, bool conv1, bool bf16, int K, int n0, std::vector<float>& wp)
+{
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++)
+            for (int ci = 0; ci < cin; ci++) {
+                const float* src = &W[(((size_t)ky * k + kx) * cin + ci) * cout];
+                const size_t kidx = conv_kidx(k, ky, kx, ci, cp, conv1, bf16);
+                for (int n = 0; n < cout; n++) wp[(size_t)(n0 + n) * K + kidx] = src[n];
+            }
+}
+// tail GEMM's 1x1 weights (1,1,mid,cout) -> [cout][64]
+inline void pack_tail(const float* Wc, int mid, int cout, std::vector<float>& w2)
+{
+    w2.assign((size_t)cout * 64, 0.f);
+    for (int k = 0; k < mid; k++)
+        for (int n = 0; n < cout; n++) w2[(size_t)n * 64 + k] = Wc[(size_t)k * cout + n];
+}
+
+// The two transposed convs (4x4, stride 2, SAME; kernels (kh,kw,Cout,Cin), vnect_model.py:188-196) as 4 sub-pixel phases of ONE
+// launch: out[2i-1+ky, 2j-1+kx, oc] += in[i,j,ic] * W[ky,kx,oc,ic]; phase (py,px) = (oy&1, ox&1):
+//   py = 0: ky = 1 reads row i', ky = 3 reads row i'-1;  py = 1: ky = 0 reads row i'+1, ky = 2 reads row i'.
+// Columns 0..127 = res5c_branch2a (BN + ReLU in the epilogue), 128..190 = res5c_branch1a's 63 deltas.
+// wp [4 phases][Npad][4 taps x 256]; dy / dx [phase * 4 + tap].
+inline void pack_deconv(const float* W1 /* (4,4,63,256) */, const float* W2 /* (4,4,128,256) */, int Npad, int K, std::vector<float>& wp,
+                        int* dy, int* dx)
+{
+    const int kys[2][2] = {{1, 3}, {0, 2}}, dys[2][2] = {{0, -1}, {1, 0}};
+    wp.assign((size_t)4 * Npad * K, 0.f);
+    for (int py = 0; py < 2; py++)
+        for (int px = 0; px < 2; px++) {
+            const int z = py * 2 + px;
+            for (int ta = 0; ta < 2; ta++)
+                for (int tb = 0; tb < 2; tb++) {
+                    const int t = ta * 2 + tb, ky = kys[py][ta], kx = kys[px][tb];
+                    dy[z * 4 + t] = dys[py][ta], dx[z * 4 + t] = dys[px][tb];
+                    for (int n = 0; n < 191; n++) {
+                        const float* src = n < 128 ? &W2[(((size_t)ky * 4 + kx) * 128 + n) * 256] : &W1[(((size_t)ky * 4 + kx) * 63 + (n - 128)) * 256];
+                        float* dst = &wp[((size_t)z * Npad + n) * K + (size_t)t * 256];
+                        memcpy(dst, src, 256 * sizeof(float));
+                    }
+                }
+        }
+}
+// FusedBatchNorm inference (contrib batch_norm default epsilon 0.001) as the epilogue's (acc + bias) * scale + shift
+inline void fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, int C, int Npad, std::vector<float>& bias,
+                    std::vector<float>& scale, std::vector<float>& shift)
+{
+    bias.assign(Npad, 0.f), scale.assign(Npad, 1.f), shift.assign(Npad, 0.f);
+    for (int c = 0; c < C; c++) {
+        bias[c] = -mean[c];
+        scale[c] = gamma[c] * (1.0f / sqrtf(var[c] + 0.001f));
+        shift[c] = beta[c];
+    }
+}
+
+// ---- activation arena ------------------------------------------------------------------------------
+// A tensor lives from the layer that first touches it (`first`) to the last (`last`); tensors with disjoint lifetimes share
+// addresses: first fit over the live intervals, in order of first use.  Returns the arena size; off[t] = byte offset of tensor t.
+inline size_t arena_first_fit(const std::vector<int>& first, const std::vector<int>& last, const std::vector<size_t>& need,
+                              std::vector<size_t>& off)
+{
+    const int nt = (int)need.size();
+    std::vector<int> order(nt);
+    for (int i = 0; i < nt; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return first[x] != first[y] ? first[x] < first[y] : x < y; });
+    off.assign(nt, 0);
+    std::vector<int> placed;
+    size_t total = 0;
+    for (int t : order) {
+        // candidate offsets: 0 and the end of every placed tensor whose lifetime overlaps; take the lowest that fits
+        std::vector<std::pair<size_t, size_t>> busy;  // [begin, end) of overlapping placed tensors
+        for (int q : placed)
+            if (!(last[q] < first[t] || last[t] < first[q])) busy.push_back({off[q], off[q] + need[q]});
+        std::sort(busy.begin(), busy.end());
+        size_t pos = 0;
+        for (auto& b : busy) {
+            if (pos + need[t] <= b.first) break;
+            pos = std::max(pos, b.second);
+        }
+        off[t] = pos, total = std::max(total, pos + need[t]);
+        placed.push_back(t);
+    }
+    return total;
+}
+
+// ---- tile shape and K split of a layer ---------------------------------------------------------------
+// Measured on MI355X with tools/sweep.sh (every layer x {64x64, 128x64, 64x128} x split 1/2/3/5 x ring depth): the 64x64 tile wins
+// everywhere (more, smaller workgroups; two per CU), and a 5-way K split pays only where a layer has at most ~half a workgroup per
+// CU and a long K loop (the 23x23 stage).  Each K slice writes its own slab and a second kernel sums the slabs in slice order, so
+// results stay deterministic.  `force` (VNECT_FORCE_TILE="BM,BN,KG,ks") overrides the choice for every layer that admits it, `plan`
+// (VNECT_PLAN="layer=BM,BN,KG,ks;layer=...") for single layers (tools/layer_table.py shows the effect).
+struct TileChoice {
+    int BM = 64, BN = 64, KG = 1, ks = 1;
+};
+inline bool tile_shape_ok(int BM, int BN, int KG) { return (BM == 64 && BN == 64 && KG == 1) || (BM == 64 && BN == 32 && KG == 2) || (BM == 32 && BN == 32 && KG == 4); }
+inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int nphase, bool bf16, const std::string& name, const char* force,
+                              const char* plan)
+{
+    TileChoice c;
+    const int nch = ntaps * cpt;
+    const int kel = K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
+    const long long mt = (M + 63) / 64, nreal = Nreal;
+    const long long tiles = mt * (round_up((int)nreal, 64) / 64) * nphase;
+    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
+        // Too few 64x64 tiles for 256 CUs and a long K: split K.  Inside the workgroup where that alone fills the chip
+        // (one workgroup per CU, four K-parallel or M/N-parallel accumulators: no slabs, no reduce launch) ...
+        const long long t64x32 = mt * (round_up((int)nreal, 32) / 32) * nphase;
+        const long long t32x32 = ((M + 31) / 32) * (round_up((int)nreal, 32) / 32) * nphase;
+        if (t64x32 > 128 && t64x32 <= 256 && cpt % 2 == 0) c.BM = 64, c.BN = 32, c.KG = 2;
+        else if (t32x32 > 128 && t32x32 <= 256 && cpt % 4 == 0) c.BM = 32, c.BN = 32, c.KG = 4;
+        // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel (bf16 loops are 2-3x shorter: there the extra
+        // launch only pays for the smallest, deepest layers)
+        else if (!bf16 || (tiles <= 64 && kel >= 2048)) c.ks = std::min(5, nch);
+    }
+    auto take = [&](const char* spec) {
+        int fBM = 0, fBN = 0, fKG = 0, fks = 0;
+        if (sscanf(spec, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) == 4 && fks >= 1 && fks <= 8 && tile_shape_ok(fBM, fBN, fKG) && cpt % fKG == 0)
+            c.BM = fBM, c.BN = fBN, c.KG = fKG, c.ks = std::max(1, std::min(fks, nch / fKG));
+    };
+    if (force) take(force);
+    if (plan) {
+        const std::string key = name + "=";
+        const char* p = strstr(plan, key.c_str());
+        if (p && (p == plan || p[-1] == ';')) take(p + key.size());
+    }
+    return c;
+}
+
+// ---- the fused stem's row groups (stem.hip) ------------------------------------------------------------
+// An image's 92 pooled rows in G groups of 4 and 5: as few tiles (S x G x 4) as one round over the 256 CUs allows (S = 3: G = 21 ->
+// 252 tiles), never more than 5 rows per tile (the LDS patch), never fewer than 4 (the halo rows are recomputed per tile).
+// row0[g] = first row of group g, row0[G] = 92.  Returns G.
+inline int stem_groups(int S, unsigned char* row0)
+{
+    int G = 256 / (4 * std::max(S, 1));
+    G = G < 19 ? 19 : (G > 23 ? 23 : G);
+    const int base = 92 / G, rem = 92 % G;
+    int r = 0;
+    for (int g = 0; g < G; g++) row0[g] = (unsigned char)r, r += base + (g < rem ? 1 : 0);
+    row0[G] = (unsigned char)r;
+    return G;
+}
+
+}  // namespace plan
+}  // namespace vnect

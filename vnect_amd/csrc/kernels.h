@@ -3,12 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "tables.h"
+
 namespace vnect {
 
-constexpr int BOX = 368;
-constexpr int HM = 46;
-constexpr int NJ = 21;
-constexpr int MAPC = 84;       // 4 maps x 21 joints
 constexpr int MAX_TAPS = 16;
 constexpr int ARG_SLABS = 8;    // arg-max workgroups per joint (6 row segments each)
 constexpr int PROF_WGS = 512;   // largest conv grid (two workgroups per CU)
@@ -106,22 +104,7 @@ hipError_t launch_strip4to3(const void* in4, float* out3, long long npix, int bf
 hipError_t launch_maxpool(const void* in, void* out, int S, int H, int W, int C, int Ho, int Wo, int bf16, hipStream_t st);
 hipError_t launch_bone(void* feat, long long npix, int ld, int bf16, hipStream_t st);
 
-// ---- pre-processing -------------------------------------------------------------------
-struct ResizeTab {  // 8-bit bilinear tables for one destination axis pair (OpenCV fixed point, 11 bits)
-    int dh, dw;       // destination size
-    int xmax;         // columns >= xmax take S[sx]*2048 (right border)
-    int copy;         // destination size == source size: plain copy
-    int16_t sx[BOX], a0[BOX], a1[BOX];
-    int16_t sy0[BOX], sy1[BOX], b0[BOX], b1[BOX];
-};
-
-struct FrameParams {  // crop GEOMETRY: depends on the crop size (H, W) only, so it is uploaded when that changes -- never
-                      // for a stream of equally sized crops
-    double scaler;
-    int offx, offy;
-    int H, W;
-    ResizeTab sq;          // squarify resize (utils.img_scale_squarify)
-};
+// ---- pre-processing (the table structs live in tables.h) -------------------------------
 struct FrameDyn {     // what does change every frame: passed to the two kernels that need it BY VALUE (kernel arguments),
                       // so a frame costs no host-to-device copy
     double t2d, t3d;
@@ -133,20 +116,9 @@ struct FrameDyn {     // what does change every frame: passed to the two kernels
     unsigned xseq;
 };
 
-struct ScaleTabs {  // per handle: pyramid resizes of the 368x368 square (utils.img_scale_padding)
-    int S;
-    int pad[8];     // leading pad rows/cols per scale
-    int scaled[8];  // 1: scale < 1 (resize + pad), 0: the square itself
-    ResizeTab t[8];
-    float lut[256]; // (float)v / 255 - 0.4 in float32
-};
-
 hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
 // ---- the stem as one launch (stem.hip): [gen_input_batch ->] conv1 + ReLU -> 3x3 / stride-2 max-pool on spatial tiles -------------
-constexpr int STEM_TW = 23;          // pooled columns per tile (92 = 4 x 23)
-constexpr int STEM_MAXH = 5;         // pooled rows per tile at most
-constexpr int STEM_MAXGROUPS = 92;   // row groups per image at most
 struct StemArgs {
     const void* batch;     // (S,368,368,4) NHWC4 batch (fp32 / bf16), or nullptr with from_frame
     const FrameParams* fp; // from_frame: the three arguments of pyramid_kernel
@@ -166,23 +138,6 @@ hipError_t launch_stem(const StemArgs& a, hipStream_t st);
 hipError_t stem_setup();  // one-time function attributes (dynamic LDS size)
 
 // ---- post-processing ------------------------------------------------------------------
-struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre crop, per scale
-    int copy;
-    int sx[HM], edge[HM];     // edge: column >= xmax -> value is S[sx]
-    float a0[HM], a1[HM];
-    int sy0[HM], sy1[HM];
-    float b0[HM], b1[HM];
-};
-struct MergeTabs {
-    int S;
-    MergeTab t[8];
-};
-struct UpTab {  // x8 upsample tables (utils.extract_2d_joints)
-    int sx[BOX], edge[BOX];
-    double a0[BOX], a1[BOX];
-    int sy0[BOX], sy1[BOX];
-    double b0[BOX], b1[BOX];
-};
 struct ArgPartial {
     double v;
     int idx;

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/vnect_abi.h"
+#include "hostplan.h"
 #include "kernels.h"
 
 using namespace vnect;
@@ -222,20 +223,8 @@ int upload(vnect_handle* h, T** dst, const std::vector<T>& v)
     return VNECT_OK;
 }
 
-// fp32 -> bf16, round to nearest even (weights are finite)
-uint16_t to_bf16(float f)
-{
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-float from_bf16(uint16_t b)
-{
-    uint32_t u = (uint32_t)b << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
+using plan::from_bf16;
+using plan::to_bf16;
 // packed weights: fp32 as is, or converted to bf16 (the device pointer is typed float* either way)
 int upload_weights(vnect_handle* h, float** dst, const std::vector<float>& v)
 {
@@ -248,77 +237,7 @@ int upload_weights(vnect_handle* h, float** dst, const std::vector<float>& v)
     return rc;
 }
 
-// ---- OpenCV INTER_LINEAR table builders (resize.cpp semantics) ----------------------
-int cv_round(double v) { return (int)nearbyint(v); }  // round half to even
-int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
-int16_t sat_short(float v)
-{
-    int r = (int)nearbyintf(v);
-    return (int16_t)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
-}
-
-struct AxisTab {
-    std::vector<int> s0, s1, edge;
-    std::vector<float> f;
-    int xmax = 0;
-};
-// x axis: offset clamped and fraction zeroed at both borders; columns >= xmax use the single tap
-AxisTab axis_x(int ssize, int dsize, double scale)
-{
-    AxisTab t;
-    t.s0.resize(dsize), t.s1.resize(dsize), t.edge.resize(dsize), t.f.resize(dsize);
-    t.xmax = dsize;
-    for (int d = 0; d < dsize; d++) {
-        float fx = (float)((d + 0.5) * scale - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= sx;
-        if (sx < 0) fx = 0, sx = 0;
-        if (sx + 1 >= ssize) {
-            t.xmax = std::min(t.xmax, d);
-            if (sx >= ssize - 1) fx = 0, sx = ssize - 1;
-        }
-        t.s0[d] = sx, t.s1[d] = std::min(sx + 1, ssize - 1), t.f[d] = fx;
-    }
-    for (int d = 0; d < dsize; d++) t.edge[d] = d >= t.xmax;
-    return t;
-}
-// y axis: floor + fraction kept; the two source rows are clipped into the image
-AxisTab axis_y(int ssize, int dsize, double scale)
-{
-    AxisTab t;
-    t.s0.resize(dsize), t.s1.resize(dsize), t.edge.assign(dsize, 0), t.f.resize(dsize);
-    for (int d = 0; d < dsize; d++) {
-        float fy = (float)((d + 0.5) * scale - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
-        t.s0[d] = clipi(sy, 0, ssize), t.s1[d] = clipi(sy + 1, 0, ssize), t.f[d] = fy;
-    }
-    return t;
-}
-
-// cv2.resize(u8 src (sh,sw), (0,0), fx=fy=f): destination size and fixed-point tables
-bool build_u8_tab(int sh, int sw, double f, ResizeTab* t)
-{
-    memset(t, 0, sizeof *t);
-    t->dw = cv_round(sw * f), t->dh = cv_round(sh * f);
-    if (t->dw < 1 || t->dh < 1 || t->dw > BOX || t->dh > BOX) return false;
-    t->copy = (t->dw == sw && t->dh == sh);
-    const double scale = 1.0 / f;
-    AxisTab x = axis_x(sw, t->dw, scale), y = axis_y(sh, t->dh, scale);
-    t->xmax = x.xmax;
-    for (int d = 0; d < t->dw; d++) {
-        t->sx[d] = (int16_t)x.s0[d];
-        t->a0[d] = sat_short((1.f - x.f[d]) * 2048.f);
-        t->a1[d] = sat_short(x.f[d] * 2048.f);
-    }
-    for (int d = 0; d < t->dh; d++) {
-        t->sy0[d] = (int16_t)y.s0[d], t->sy1[d] = (int16_t)y.s1[d];
-        t->b0[d] = sat_short((1.f - y.f[d]) * 2048.f);
-        t->b1[d] = sat_short(y.f[d] * 2048.f);
-    }
-    return true;
-}
-
+// ---- tables: the arithmetic is in hostplan.h (HIP-free, sanitizer-tested on the CPU box); here they are built and uploaded ----
 int build_scale_tables(vnect_handle* h)
 {
     ScaleTabs st;
@@ -326,32 +245,11 @@ int build_scale_tables(vnect_handle* h)
     MergeTabs mt;
     memset(&mt, 0, sizeof mt);
     st.S = mt.S = h->S;
-    for (int v = 0; v < 256; v++) st.lut[v] = (float)v / 255.f - 0.4f;  // float32: batch / 255 - 0.4
+    plan::fill_lut(st.lut);
     for (int i = 0; i < h->S; i++) {
         const double s = h->cfg.scales[i];
-        if (!(s > 0.0) || s > 1.0) return fail(h, VNECT_E_ARG, "scales must be in (0, 1]");
-        // estimator.py:77: `img_scale_padding(...) if scale < 1 else img_square`
-        st.scaled[i] = s < 1.0;
-        if (st.scaled[i]) {
-            if (!build_u8_tab(BOX, BOX, s, &st.t[i])) return fail(h, VNECT_E_ARG, "scale too small");
-            st.pad[i] = (BOX - st.t[i].dh) / 2;  // utils.py:137-140; the remainder pads the far side
-        }
-        // estimator.py:112-119: rescale = 1.0 / scale; cv2.resize(map, fx=fy=rescale); centre crop 46x46
-        const double f = 1.0 / s;
-        const int ds = cv_round(HM * f);
-        if (ds < HM) return fail(h, VNECT_E_ARG, "scale > 1 not supported");
-        MergeTab& m = mt.t[i];
-        m.copy = ds == HM;
-        const double scale = 1.0 / f;
-        AxisTab x = axis_x(HM, ds, scale), y = axis_y(HM, ds, scale);
-        const int off = ds / 2 - HM / 2;
-        for (int r = 0; r < HM; r++) {
-            const int d = r + off;
-            m.sx[r] = x.s0[d], m.edge[r] = x.edge[d];
-            m.a0[r] = 1.f - x.f[d], m.a1[r] = x.f[d];
-            m.sy0[r] = y.s0[d], m.sy1[r] = y.s1[d];
-            m.b0[r] = 1.f - y.f[d], m.b1[r] = y.f[d];
-        }
+        if (const char* why = plan::build_scale_tab(s, &st, i)) return fail(h, VNECT_E_ARG, why);
+        if (const char* why = plan::build_merge_tab(s, &mt.t[i])) return fail(h, VNECT_E_ARG, why);
     }
     HIPCK(h, hipMemcpy(h->d_stabs, &st, sizeof st, hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_mtabs, &mt, sizeof mt, hipMemcpyHostToDevice));
@@ -360,22 +258,9 @@ int build_scale_tables(vnect_handle* h)
 
 int build_up_table(vnect_handle* h)
 {
-    // utils.py:169-171: cv2.resize(hm (46,46) f64, fx=fy=8) -> 368x368
     std::vector<UpTab> u(1);
-    AxisTab x = axis_x(HM, BOX, 1.0 / 8.0), y = axis_y(HM, BOX, 1.0 / 8.0);
-    for (int d = 0; d < BOX; d++) {
-        u[0].sx[d] = x.s0[d], u[0].edge[d] = x.edge[d];
-        u[0].a0[d] = (double)(1.f - x.f[d]), u[0].a1[d] = (double)x.f[d];
-        u[0].sy0[d] = y.s0[d], u[0].sy1[d] = y.s1[d];
-        u[0].b0[d] = (double)(1.f - y.f[d]), u[0].b1[d] = (double)y.f[d];
-    }
-    // heat_argmax_kernel walks the rows by (segment, phase); make sure the table really has that structure
-    for (int d = 0; d < BOX; d++) {
-        const int g = (d + 4) / 8, ph = (d + 4) % 8;
-        if (u[0].sy0[d] != std::max(g - 1, 0) || u[0].sy1[d] != std::min(g, HM - 1) || u[0].b0[d] != u[0].b0[4 + ph] ||
-            u[0].b1[d] != u[0].b1[4 + ph])
-            return fail(h, VNECT_E_STATE, "internal: x8 upsample table does not have the segment/phase structure");
-    }
+    // heat_argmax_kernel walks the rows by (segment, phase): plan::build_up_tab checks that the table really has that structure
+    if (!plan::build_up_tab(&u[0])) return fail(h, VNECT_E_STATE, "internal: x8 upsample table does not have the segment/phase structure");
     HIPCK(h, hipMemcpy(h->d_up, u.data(), sizeof(UpTab), hipMemcpyHostToDevice));
     return VNECT_OK;
 }
@@ -383,18 +268,9 @@ int build_up_table(vnect_handle* h)
 // utils.img_scale_squarify + img_padding geometry for an (H,W) frame
 int squarify_params(vnect_handle* h, int H, int W, FrameParams* fp)
 {
-    if (H < 1 || W < 1 || H > 8192 || W > 8192) return fail(h, VNECT_E_ARG, "frame size out of range");
     if (h->sq_H != H || h->sq_W != W) {
         FrameParams c;
-        memset(&c, 0, sizeof c);
-        c.scaler = (double)BOX / std::max(H, W);
-        if (!build_u8_tab(H, W, c.scaler, &c.sq)) return fail(h, VNECT_E_ARG, "squarify: scaled size exceeds 368");
-        const int h2 = c.sq.dh, w2 = c.sq.dw;
-        // utils.py:98-103 indexes a 368-long axis with the scaled long side; numpy raises if it is not 368
-        if ((h2 > w2 ? h2 : w2) != BOX) return fail(h, VNECT_E_ARG, "squarify: scaled long side != 368");
-        if (h2 > w2) c.offx = BOX / 2 - w2 / 2;
-        else c.offy = BOX / 2 - h2 / 2;
-        c.H = H, c.W = W;
+        if (const char* why = plan::squarify(H, W, &c)) return fail(h, VNECT_E_ARG, why);
         h->sq_cache = c, h->sq_H = H, h->sq_W = W;
     }
     *fp = h->sq_cache;
@@ -426,57 +302,16 @@ const HostArray* get_w(vnect_handle* h, const std::string& name, std::vector<int
     return &it->second;
 }
 
-void same_pad(int in, int k, int stride, int* out, int* before)
-{
-    *out = (in + stride - 1) / stride;
-    int tot = std::max((*out - 1) * stride + k - in, 0);
-    *before = tot / 2;
-}
+using plan::round_up;
+using plan::same_pad;
 
-int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-// Tile and K-split of a layer.  Measured on MI355X with tools/sweep.sh (every layer x {64x64, 128x64, 64x128}
-// x split 1/2/3/5 x ring depth): the 64x64 tile wins everywhere (more, smaller workgroups; two per CU), and a
-// 5-way K split pays only where a layer has at most ~half a workgroup per CU and a long K loop (the 23x23 stage).
-// Each K slice writes its own slab and a second kernel sums the slabs in slice order, so results stay
-// deterministic.  VNECT_FORCE_TILE="BM,BN,ks" overrides the choice for experiments.
+// Tile and K-split of a layer: plan::choose_tile (hostplan.h) with the tuning overrides VNECT_FORCE_TILE / VNECT_PLAN.
 void choose_tile(Layer& L, long long npix)
 {
     (void)npix;
-    const int nch = L.a.ntaps * L.a.cpt;
-    const int kel = L.a.K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
-    int BM = 64, BN = 64, KG = 1, ks = 1;
-    const long long mt = (L.a.M + 63) / 64, nreal = L.Nreal;
-    const long long tiles = mt * (round_up((int)nreal, 64) / 64) * L.a.nphase;
-    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
-        // Too few 64x64 tiles for 256 CUs and a long K: split K.  Inside the workgroup where that alone fills the chip
-        // (one workgroup per CU, four K-parallel or M/N-parallel accumulators: no slabs, no reduce launch) ...
-        const long long t64x32 = mt * (round_up((int)nreal, 32) / 32) * L.a.nphase;
-        const long long t32x32 = ((L.a.M + 31) / 32) * (round_up((int)nreal, 32) / 32) * L.a.nphase;
-        if (t64x32 > 128 && t64x32 <= 256 && L.a.cpt % 2 == 0) BM = 64, BN = 32, KG = 2;
-        else if (t32x32 > 128 && t32x32 <= 256 && L.a.cpt % 4 == 0) BM = 32, BN = 32, KG = 4;
-        // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel (bf16 loops are 2-3x shorter: there the extra
-        // launch only pays for the smallest, deepest layers)
-        else if (!L.a.bf16 || (tiles <= 64 && kel >= 2048)) ks = std::min(5, nch);
-    }
-    const char* force = getenv("VNECT_FORCE_TILE");  // tuning: "BM,BN,KG,ks" for every layer that admits it
-    if (force) {
-        int fBM = 0, fBN = 0, fKG = 0, fks = 0;
-        if (sscanf(force, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) == 4 && fks >= 1 && fks <= 8 && L.a.cpt % std::max(fKG, 1) == 0 &&
-            ((fBM == 64 && fBN == 64 && fKG == 1) || (fBM == 64 && fBN == 32 && fKG == 2) || (fBM == 32 && fBN == 32 && fKG == 4)))
-            BM = fBM, BN = fBN, KG = fKG, ks = std::min(fks, nch / fKG);
-    }
-    // tuning: VNECT_PLAN="layer=BM,BN,KG,ks;layer=..." overrides single layers (tools/layer_table.py shows the effect)
-    if (const char* plan = getenv("VNECT_PLAN")) {
-        const std::string key = L.name + "=";
-        const char* p = strstr(plan, key.c_str());
-        int fBM = 0, fBN = 0, fKG = 0, fks = 0;
-        if (p && (p == plan || p[-1] == ';') && sscanf(p + key.size(), "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) == 4 && fks >= 1 && fks <= 8 &&
-            L.a.cpt % std::max(fKG, 1) == 0 &&
-            ((fBM == 64 && fBN == 64 && fKG == 1) || (fBM == 64 && fBN == 32 && fKG == 2) || (fBM == 32 && fBN == 32 && fKG == 4)))
-            BM = fBM, BN = fBN, KG = fKG, ks = std::min(fks, nch / fKG);
-    }
-    L.BM = BM, L.BN = BN, L.KG = KG, L.a.ksplit = ks;
+    const plan::TileChoice c = plan::choose_tile(L.a.M, L.Nreal, L.a.ntaps, L.a.cpt, L.a.K, L.a.nphase, L.a.bf16 != 0, L.name,
+                                                 getenv("VNECT_FORCE_TILE"), getenv("VNECT_PLAN"));
+    L.BM = c.BM, L.BN = c.BN, L.KG = c.KG, L.a.ksplit = c.ks;
 }
 
 struct ConvSpec {
@@ -537,14 +372,7 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     choose_tile(L, (long long)a.M);
     a.Npad = round_up(sp.cout, L.BN);
     std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
-    for (int ky = 0; ky < sp.k; ky++)
-        for (int kx = 0; kx < sp.k; kx++)
-            for (int ci = 0; ci < cin; ci++) {
-                const float* src = &W->d[(((size_t)ky * sp.k + kx) * cin + ci) * sp.cout];
-                const size_t kidx = conv1 ? (h->bf16 ? (size_t)(ky >> 1) * 64 + (ky & 1) * 32 + kx * 4 + ci : (size_t)ky * 32 + kx * 4 + ci)
-                                          : (size_t)(ky * sp.k + kx) * cp + ci;
-                for (int n = 0; n < sp.cout; n++) wp[(size_t)n * a.K + kidx] = src[n];
-            }
+    plan::pack_conv(W->d.data(), sp.k, cin, sp.cout, cp, conv1, h->bf16, a.K, 0, wp);
     for (int n = 0; n < sp.cout; n++) bp[n] = B->d[n];
     if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
     h->layers.push_back(L);
@@ -593,12 +421,8 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     if (L.BN != 64 || L.a.ksplit != 1 || L.KG != 1) L.BM = 64, L.BN = 64, L.KG = 1, L.a.ksplit = 1;  // the column split relies on 64-wide tiles, no slabs
     a.Npad = round_up(L.Nreal, 64);
     std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
-    for (int t = 0; t < k * k; t++)
-        for (int ci = 0; ci < cin; ci++) {
-            const size_t kidx = (size_t)t * tin.Cs + ci;
-            for (int n = 0; n < cout_a; n++) wp[(size_t)n * a.K + kidx] = Wa->d[((size_t)t * cin + ci) * cout_a + n];
-            for (int n = 0; n < cout_b; n++) wp[(size_t)(cout_a + n) * a.K + kidx] = Wb->d[((size_t)t * cin + ci) * cout_b + n];
-        }
+    plan::pack_conv(Wa->d.data(), k, cin, cout_a, tin.Cs, false, h->bf16, a.K, 0, wp);
+    plan::pack_conv(Wb->d.data(), k, cin, cout_b, tin.Cs, false, h->bf16, a.K, cout_a, wp);
     for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
     for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
     if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
@@ -645,13 +469,10 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     L.flops = 2.0 * a.M * ((double)L.Kreal * mid + (double)mid * cout);
     L.BM = 64, L.BN = 64, L.KG = 1, a.ksplit = 1;
     a.Npad = 64;
-    std::vector<float> wp((size_t)64 * a.K, 0.f), bp(64, 0.f), w2((size_t)cout * 64, 0.f), b2(cout, 0.f);
-    for (int t = 0; t < 9; t++)
-        for (int ci = 0; ci < cin; ci++)
-            for (int n = 0; n < mid; n++) wp[(size_t)n * a.K + (size_t)t * tin.Cs + ci] = Wb->d[((size_t)t * cin + ci) * mid + n];
+    std::vector<float> wp((size_t)64 * a.K, 0.f), bp(64, 0.f), w2, b2(cout, 0.f);
+    plan::pack_conv(Wb->d.data(), 3, cin, mid, tin.Cs, false, h->bf16, a.K, 0, wp);
     for (int n = 0; n < mid; n++) bp[n] = Bb->d[n];
-    for (int k = 0; k < mid; k++)
-        for (int n = 0; n < cout; n++) w2[(size_t)n * 64 + k] = Wc->d[(size_t)k * cout + n];
+    plan::pack_tail(Wc->d.data(), mid, cout, w2);
     for (int n = 0; n < cout; n++) b2[n] = Bc->d[n];
     float *dw2 = nullptr, *db2 = nullptr;
     if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
@@ -694,15 +515,8 @@ void setup_stem(vnect_handle* h)
     a.batch = tin.d, a.w = C.w, a.bias = C.bias, a.out = tp.d;
     a.fp = h->d_fp, a.tabs = h->d_stabs;
     a.S = h->Snet, a.scale_base = h->sharded ? h->cfg.pyramid_rank : 0, a.bf16 = h->bf16;
-    // row groups of 4 and 5 pooled rows: as few tiles as one round over the 256 CUs allows (S = 3: 21 groups -> 252 tiles),
-    // never more than 5 rows per tile (the LDS patch), never fewer than 4 (the halo rows are recomputed per tile)
-    int G = 256 / (4 * a.S);
-    G = G < 19 ? 19 : (G > 23 ? 23 : G);
-    a.groups = G;
-    const int base = 92 / G, rem = 92 % G;
-    int r = 0;
-    for (int g = 0; g < G; g++) a.row0[g] = (unsigned char)r, r += base + (g < rem ? 1 : 0);
-    a.row0[G] = (unsigned char)r;
+    // row groups of 4 and 5 pooled rows (hostplan.h)
+    a.groups = plan::stem_groups(a.S, a.row0);
 }
 
 int finalize_impl(vnect_handle* h)
@@ -861,30 +675,10 @@ int finalize_impl(vnect_handle* h)
         choose_tile(L, (long long)S * 46 * 46);
         a.Npad = round_up(191, L.BN);
         a.w_phase_stride = (long long)a.Npad * a.K;
-        const int kys[2][2] = {{1, 3}, {0, 2}}, dys[2][2] = {{0, -1}, {1, 0}};
-        std::vector<float> wp((size_t)4 * a.Npad * a.K, 0.f);
-        for (int py = 0; py < 2; py++)
-            for (int px = 0; px < 2; px++) {
-                const int z = py * 2 + px;
-                for (int ta = 0; ta < 2; ta++)
-                    for (int tb = 0; tb < 2; tb++) {
-                        const int t = ta * 2 + tb, ky = kys[py][ta], kx = kys[px][tb];
-                        L.dy[z * 4 + t] = (int)dys[py][ta], L.dx[z * 4 + t] = (int)dys[px][tb];
-                        for (int n = 0; n < 191; n++) {
-                            const float* src = n < 128 ? &W2->d[(((size_t)ky * 4 + kx) * 128 + n) * 256]
-                                                       : &W1->d[(((size_t)ky * 4 + kx) * 63 + (n - 128)) * 256];
-                            float* dst = &wp[((size_t)z * a.Npad + n) * a.K + (size_t)t * 256];
-                            memcpy(dst, src, 256 * sizeof(float));
-                        }
-                    }
-            }
+        std::vector<float> wp, bp, sc, sh;
+        plan::pack_deconv(W1->d.data(), W2->d.data(), a.Npad, a.K, wp, L.dy, L.dx);
         // FusedBatchNorm inference (contrib batch_norm default epsilon 0.001): (x - mean) * (gamma * rsqrt(var + eps)) + beta
-        std::vector<float> bp(a.Npad, 0.f), sc(a.Npad, 1.f), sh(a.Npad, 0.f);
-        for (int c = 0; c < 128; c++) {
-            bp[c] = -mu->d[c];
-            sc[c] = ga->d[c] * (1.0f / sqrtf(va->d[c] + 0.001f));
-            sh[c] = be->d[c];
-        }
+        plan::fold_bn(ga->d.data(), be->d.data(), mu->d.data(), va->d.data(), 128, a.Npad, bp, sc, sh);
         if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
             return VNECT_E_HIP;
         // bone-length features (vnect_model.py:198-209): inside this launch (conv.hip, FUSE = 2) where every workgroup has one tile,
@@ -938,28 +732,12 @@ int finalize_impl(vnect_handle* h)
             touch(L.in, l), touch(L.resid, l), touch(L.out, l), touch(L.out2, l);
         }
         touch(h->t_out, nl);  // read by the post-processing
-        std::vector<int> order(nt);
-        for (int i = 0; i < nt; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return first[x] != first[y] ? first[x] < first[y] : x < y; });
-        std::vector<size_t> off(nt, 0);
-        std::vector<int> placed;
-        size_t total = 0;
-        for (int t : order) {
+        std::vector<size_t> need(nt), off;
+        for (int t = 0; t < nt; t++) {
             if (last[t] < first[t]) first[t] = -1, last[t] = nl;  // never touched by a layer: keep it private
-            const size_t need = padded(h->tensors[t]);
-            // candidate offsets: 0 and the end of every placed tensor whose lifetime overlaps; take the lowest that fits
-            std::vector<std::pair<size_t, size_t>> busy;  // [begin, end) of overlapping placed tensors
-            for (int q : placed)
-                if (!(last[q] < first[t] || last[t] < first[q])) busy.push_back({off[q], off[q] + padded(h->tensors[q])});
-            std::sort(busy.begin(), busy.end());
-            size_t pos = 0;
-            for (auto& b : busy) {
-                if (pos + need <= b.first) break;
-                pos = std::max(pos, b.second);
-            }
-            off[t] = pos, total = std::max(total, pos + need);
-            placed.push_back(t);
+            need[t] = padded(h->tensors[t]);
         }
+        const size_t total = plan::arena_first_fit(first, last, need, off);
         char* base = nullptr;
         int rc = dev_alloc(h, &base, total);
         if (rc) return rc;
