@@ -371,5 +371,31 @@ inline int stem_groups(int S, unsigned char* row0)
     return G;
 }
 
+// The from-the-frame form of the stem lands, per tile, the rectangle of the square its input patch is made from in LDS (stem.hip, phase
+// B): at most STEM_REG_ROWS rows of STEM_REG_PITCH bytes.  True if that holds for EVERY tile of every image at these scales -- the same
+// bounds arithmetic as the kernel's, on the host's copy of the tables (scales below ~0.48 need more and take the batch-tensor form).
+inline bool stem_frame_fits(const ScaleTabs& st, int S, int scale_base, int groups, const unsigned char* row0, bool bf16)
+{
+    for (int sI = 0; sI < S; sI++) {
+        const int s = sI + scale_base;
+        if (s < 0 || s >= 8) return false;
+        const ResizeTab& t = st.t[s];
+        const bool scaled = st.scaled[s] != 0, resize = scaled && !t.copy;
+        const int off = scaled ? st.pad[s] : 0, dh = scaled ? t.dh : BOX, dw = scaled ? t.dw : BOX;
+        for (int g = 0; g < groups; g++)
+            for (int c = 0; c < 4; c++) {
+                const int h = row0[g + 1] - row0[g], nrow = 2 * h + 1, prow = 2 * nrow + (bf16 ? 6 : 5);
+                const int iy0 = 4 * row0[g] - 2, ix0 = 4 * STEM_TW * c - 2;
+                const int ylo = std::max(iy0, off), yhi = std::min(iy0 + prow - 1, off + dh - 1);
+                const int xlo = std::max(ix0, off), xhi = std::min(ix0 + STEM_PW - 1, off + dw - 1);
+                if (ylo > yhi || xlo > xhi) continue;
+                const int qy0 = resize ? t.sy0[ylo - off] : ylo - off, qy1 = resize ? t.sy1[yhi - off] : yhi - off;
+                const int qx0 = resize ? t.sx[xlo - off] : xlo - off, qx1 = resize ? std::min(t.sx[xhi - off] + 1, BOX - 1) : xhi - off;
+                if (qy1 - qy0 + 1 > STEM_REG_ROWS || 3 * (qx1 - qx0 + 1) + 8 > STEM_REG_PITCH) return false;
+            }
+    }
+    return true;
+}
+
 }  // namespace plan
 }  // namespace vnect

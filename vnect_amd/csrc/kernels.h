@@ -132,6 +132,7 @@ struct StemArgs {
     int S, groups;         // images; row groups per image (grid = S * groups * 4 tiles)
     int scale_base;        // from_frame: image 0 of the batch is scale `scale_base` (a pyramid-sharded rank)
     int bf16, from_frame;
+    int dbg;               // tuning only (VNECT_STEM_DBG): 1 = no conv blocks, 2 = no pooling, 4 = no patch (timing breakdowns; wrong results)
     unsigned char row0[STEM_MAXGROUPS + 1];  // first pooled row of every group; row0[groups] = 92
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t st);

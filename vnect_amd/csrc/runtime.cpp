@@ -74,6 +74,8 @@ struct vnect_handle {
     // The stem as one launch (stem.hip): conv1 + pool1 [+ gen_input_batch].  0: off (the stand-alone layers), 1: from the batch
     // tensor (behind pyramid_kernel; also what vnect_forward uses), 2: from the frame (no pyramid launch, no batch tensor).
     int stem_mode = 0;
+    bool stem_frame_ok = false;  // every tile's rectangle of frame bytes fits the kernel's LDS scratch at the current scales
+    ScaleTabs stabs_host{};      // the host's copy of d_stabs (plan::stem_frame_fits reads it)
     int l_conv1 = -1, l_pool1 = -1;  // the two layers a stem launch stands for
     StemArgs stem{};
     float* in3 = nullptr;  // (S,368,368,3) staging for vnect_forward / preprocess read-back
@@ -253,6 +255,11 @@ int build_scale_tables(vnect_handle* h)
     }
     HIPCK(h, hipMemcpy(h->d_stabs, &st, sizeof st, hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_mtabs, &mt, sizeof mt, hipMemcpyHostToDevice));
+    h->stabs_host = st;
+    for (vnect_handle* q : std::vector<vnect_handle*>(1, h)) {  // (lanes share d_stabs; their eligibility follows lane 0's below)
+        if (q->stem_mode == 2) q->stem_frame_ok = plan::stem_frame_fits(st, q->stem.S, q->stem.scale_base, q->stem.groups, q->stem.row0, q->bf16);
+    }
+    for (vnect_handle* tw : h->twins) tw->stem_frame_ok = h->stem_frame_ok;
     return VNECT_OK;
 }
 
@@ -517,6 +524,8 @@ void setup_stem(vnect_handle* h)
     a.S = h->Snet, a.scale_base = h->sharded ? h->cfg.pyramid_rank : 0, a.bf16 = h->bf16;
     // row groups of 4 and 5 pooled rows (hostplan.h)
     a.groups = plan::stem_groups(a.S, a.row0);
+    const vnect_handle* tabs_owner = h;  // a lane's tables are lane 0's: build_twin copies stabs_host before calling this
+    h->stem_frame_ok = h->stem_mode == 2 && plan::stem_frame_fits(tabs_owner->stabs_host, a.S, a.scale_base, a.groups, a.row0, h->bf16);
 }
 
 int finalize_impl(vnect_handle* h)
@@ -851,11 +860,21 @@ int sync_geometry(vnect_handle* h, const FrameParams& fp)
 
 int run_pre(vnect_handle* h, const FrameDyn& dyn, bool timed = false, bool want_batch = false)
 {
-    if (h->stem_mode == 2 && !want_batch) {  // gen_input_batch + conv1 + pool1 in one launch: the batch tensor is never written
+    if (h->stem_mode == 2 && !want_batch) {
         StemArgs a = h->stem;
-        a.from_frame = 1, a.dyn = dyn;
         a.prof = timed ? h->d_prof + PROF_SLOTS * h->l_conv1 : nullptr;
         a.prof_end = timed ? h->d_prof_end + (size_t)PROF_WGS * h->l_conv1 : nullptr;
+        // gen_input_batch + conv1 + pool1 in ONE launch, the batch tensor never written: for frames whose squarify step is a copy (long
+        // side == 368) at scales whose rectangles fit the kernel's scratch.  Any other frame: pyramid_kernel, then the stem from the
+        // batch tensor -- both in front of the graph, which starts at res2a either way.  Same results bit for bit.
+        if (h->stem_frame_ok && h->fp_dev_valid && h->fp_dev.sq.copy) {
+            a.from_frame = 1, a.dyn = dyn;
+            HIPCK(h, launch_stem(a, h->st));
+            return VNECT_OK;
+        }
+        HIPCK(h, launch_pyramid(h->d_fp, dyn, h->d_stabs, h->tensors[h->t_input4].d, h->Snet,
+                                h->sharded ? h->cfg.pyramid_rank : 0, h->bf16, h->st));
+        a.from_frame = 0;
         HIPCK(h, launch_stem(a, h->st));
         return VNECT_OK;
     }
@@ -1097,6 +1116,7 @@ int build_twin(vnect_handle* h)
     for (Layer& L : t->layers)
         if (L.op == OP_CONV) bind_activations(t, L);
     t->l_conv1 = h->l_conv1, t->l_pool1 = h->l_pool1;
+    t->stabs_host = h->stabs_host;
     setup_stem(t);  // same plan as lane 0, this lane's arena and geometry block
     t->finalized = true;
     if ((rc = build_graph(t))) return fail(h, rc, t->err);
@@ -1335,6 +1355,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         const bool pre = cfg->preprocess_only != 0;
         h->pre_only = pre;
         if (h->cfg.max_frame_bytes <= 0) h->cfg.max_frame_bytes = 4096 * 4096 * 3;
+        if (h->cfg.max_frame_bytes < INT32_MAX - 16) h->cfg.max_frame_bytes = (h->cfg.max_frame_bytes + 15) & ~15;  // slots start 16-byte aligned (the stem reads frame rows as aligned dwords)
         if (h->cfg.num_frame_slots <= 0) h->cfg.num_frame_slots = 4;
         // gen_input_batch alone (the static method creates and destroys such a handle per call): ONE frame slot that grows with the
         // frames it is given (upload_frame_impl), no gather buffer, no filter bank, no profiling buffers -- the resize tables and the
@@ -1347,7 +1368,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         HIPCK(h, stem_setup());
         h->slots.resize(h->cfg.num_frame_slots);
         int rc;
-        if (!pre && (rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes))) return rc;
+        if (!pre && (rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes + 16))) return rc;  // + slack: a dword read may run 3 bytes past a frame's last pixel
         if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;

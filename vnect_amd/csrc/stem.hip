@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include "pyramid.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace vnect {
@@ -36,14 +37,34 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int STEM_CW = 2 * STEM_TW + 1;             // conv columns per tile (47)
-constexpr int STEM_PW = 100;                         // patch row stride in pixels (99 used; even, so a bf16 pixel pair is 16-byte aligned)
+constexpr int STEM_LW = 48;                          // row stride of the tile's conv pixels in M (47 + one dummy): a lane's groups of four
+                                                     // consecutive M rows then start at a column that is a multiple of 4 and never cross a row
 constexpr int STEM_PH = 2 * (2 * STEM_MAXH + 1) + 6; // patch rows at most: 27, + 1 for the bf16 form's zero-weight eighth filter row
 constexpr int STEM_THREADS = 512;
 
-template <bool BF>
-constexpr size_t stem_lds() { return (size_t)STEM_PH * STEM_PW * 4 * (BF ? 2 : 4) + (size_t)STEM_MAXH * STEM_TW * 64 * 4; }
+// FRAME form: scratch behind the pooled tile -- the `/255 - 0.4` table, one descriptor per patch row / column, and the rectangle of the
+// frame the tile's patch is made from, as raw bytes (rows of STEM_REG_PITCH bytes)
+struct StemRow {   // patch row pr = canvas row iy0 + pr
+    short kind;    // 0: outside the 368 x 368 canvas (the conv's zero padding); 1: black canvas outside the scaled image;
+                   // 2: a row of the square itself (q0); 3: blend of square rows q0, q1 with weights b0, b1 (OpenCV fixed point)
+    short q0, q1, b0, b1;
+    short fill_[3];
+};
+struct StemCol {   // patch column pc = canvas column ix0 + pc; kind 3: taps q, q + 1 with weights a0, a1; 4: the single tap q (right border)
+    short kind, q, a0, a1;
+};
+constexpr int STEM_SCR_LUT = 0, STEM_SCR_ROWS = 1024, STEM_SCR_COLS = STEM_SCR_ROWS + 16 * 32, STEM_SCR_MIS = STEM_SCR_COLS + 8 * 104,
+              STEM_SCR_REG = STEM_SCR_MIS + 4 * STEM_REG_ROWS, STEM_SCR_BYTES = STEM_SCR_REG + STEM_REG_ROWS * STEM_REG_PITCH;
+static_assert(STEM_SCR_REG % 16 == 0 && STEM_PH <= 32 && STEM_PW <= 104, "scratch layout");
 
-// FRAME: the patch is computed from the uint8 frame (pyramid.h) instead of being copied from the batch tensor
+template <bool BF, bool FRAME = false>
+constexpr size_t stem_lds()
+{
+    return (size_t)STEM_PH * STEM_PW * 4 * (BF ? 2 : 4) + (size_t)STEM_MAXH * STEM_TW * 64 * 4 + (FRAME ? STEM_SCR_BYTES : 0);
+}
+
+// FRAME: the patch is computed from the uint8 frame instead of being copied from the batch tensor (the host takes this form only for
+// frames whose squarify step is a copy, and only if every tile's rectangle fits the scratch: plan::stem_frame_fits)
 template <bool BF, bool FRAME, bool PROF>
 __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 {
@@ -61,7 +82,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
     const int r0 = a.row0[g], r1 = a.row0[g + 1], h = r1 - r0;     // pooled rows [r0, r1) of image sI
     const int cy0 = 2 * r0, cx0 = 2 * STEM_TW * c;                  // first conv row / column of the tile
     const int nrow = 2 * h + 1;                                    // conv rows 2 r0 .. 2 r1
-    const int npix = nrow * STEM_CW, nblk = (npix + 31) >> 5;
+    const int npix = nrow * STEM_LW, nblk = (npix + 31) >> 5;  // M = conv pixels in rows of 48 (column 47 is a dummy)
     // patch rows: input rows 2 cy0 - 2 .. 2 (cy0 + nrow - 1) + 4; the bf16 form walks K in row PAIRS, so its (zero-weight) eighth
     // filter row reads one row more -- filled with the real input like every other, so that even the signs of the zero products
     // match the stand-alone kernel's.  Same for the zero-weight eighth pixel of a row (patch column 99).
@@ -94,16 +115,117 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 
     // ---- 1. the input patch --------------------------------------------------------------------------------------------
     for (int i = tid; i < h * STEM_TW * 16; i += STEM_THREADS) ((f32x4*)pooled)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (FRAME) {
+    if (a.dbg & 4) {
+        for (int i = tid; i < prow * STEM_PW; i += STEM_THREADS) ((tx4*)patch)[i] = tx4{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    } else if constexpr (FRAME) {
+        // gen_input_batch for this tile (estimator.py:70-81; the arithmetic of pyramid.h, which pyramid_kernel evaluates pixel by pixel
+        // with ~16 dependent byte gathers each): here the frame bytes the whole patch needs are landed ONCE, as aligned dwords, and
+        // every table entry the patch needs is in LDS before the first pixel is computed -- three short phases, no global load in the
+        // per-pixel code.  Only for frames whose squarify step is a copy (frame long side == 368: square(y, x) = frame[y - offy][x -
+        // offx] or black).
+        char* scr = (char*)(pooled + STEM_MAXH * STEM_TW * 64);
+        float* lut = (float*)(scr + STEM_SCR_LUT);
+        StemRow* rows = (StemRow*)(scr + STEM_SCR_ROWS);
+        StemCol* cols = (StemCol*)(scr + STEM_SCR_COLS);
+        int* rowmis = (int*)(scr + STEM_SCR_MIS);
+        unsigned char* reg = (unsigned char*)(scr + STEM_SCR_REG);
         const int s = sI + a.scale_base;
+        const ResizeTab& t = a.tabs->t[s];
+        const int scaled = a.tabs->scaled[s];
+        const bool resize = scaled && !t.copy;       // (a scale whose size rounds to 368 is a plain copy of the square)
+        const int off = scaled ? a.tabs->pad[s] : 0;  // origin and size of the scaled image on the canvas
+        const int dh = scaled ? t.dh : BOX, dw = scaled ? t.dw : BOX;
+        const int offy = a.fp->offy, offx = a.fp->offx, FH = a.fp->sq.dh, FW = a.fp->sq.dw;  // the frame inside the square
+        // -- A: tables -> LDS
+        if (tid < 256) lut[tid] = a.tabs->lut[tid];
+        if (tid < prow) {
+            const int y = iy0 + tid, dy = y - off;
+            StemRow r = {0, 0, 0, 0, 0, {0, 0, 0}};
+            if ((unsigned)y < (unsigned)BOX) {
+                if ((unsigned)dy >= (unsigned)dh) r.kind = 1;
+                else if (!resize) r.kind = 2, r.q0 = r.q1 = (short)dy;
+                else r.kind = 3, r.q0 = t.sy0[dy], r.q1 = t.sy1[dy], r.b0 = t.b0[dy], r.b1 = t.b1[dy];
+            }
+            rows[tid] = r;
+        }
+        if (tid >= 128 && tid < 128 + STEM_PW) {
+            const int x = ix0 + tid - 128, dx = x - off;
+            StemCol q = {0, 0, 0, 0};
+            if ((unsigned)x < (unsigned)BOX) {
+                if ((unsigned)dx >= (unsigned)dw) q.kind = 1;
+                else if (!resize) q.kind = 2, q.q = (short)dx;
+                else q.kind = dx < t.xmax ? 3 : 4, q.q = t.sx[dx], q.a0 = t.a0[dx], q.a1 = t.a1[dx];
+            }
+            cols[tid - 128] = q;
+        }
+        __syncthreads();
+        // -- B: the rectangle of the square the patch reads, [qy0, qy1] x [qx0, qx1] (from the first / last patch row and column that lie
+        //    inside the scaled image), as frame bytes.  LDS row r holds square row qy0 + r; pixel qx sits at byte 3 (qx - qx0) +
+        //    rowmis[r], the offset chosen so that LDS dwords and global dwords are aligned to each other; bytes outside the frame stay 0.
+        const int ylo = iy0 > off ? iy0 : off, yhi = (iy0 + prow - 1 < off + dh - 1 ? iy0 + prow - 1 : off + dh - 1);
+        const int xlo = ix0 > off ? ix0 : off, xhi = (ix0 + STEM_PW - 1 < off + dw - 1 ? ix0 + STEM_PW - 1 : off + dw - 1);
+        int qy0 = 0, qx0 = 0, RH = 0, RW = 0;
+        if (ylo <= yhi && xlo <= xhi) {
+            qy0 = rows[ylo - iy0].q0, qx0 = cols[xlo - ix0].q;
+            const int qy1 = rows[yhi - iy0].q1;
+            int qx1 = cols[xhi - ix0].q + (resize ? 1 : 0);
+            if (qx1 > BOX - 1) qx1 = BOX - 1;
+            RH = qy1 - qy0 + 1, RW = qx1 - qx0 + 1;  // <= STEM_REG_ROWS, 3 RW + 8 <= STEM_REG_PITCH: plan::stem_frame_fits
+        }
+        {
+            constexpr int RPW = STEM_REG_PITCH / 4, PER = STEM_REG_ROWS * RPW / STEM_THREADS;  // 20 dwords per thread at most
+            const int fx0 = qx0 - offx;                             // frame column of square column qx0 (may be negative)
+            const int fxL = fx0 > 0 ? fx0 : 0, fxR = (fx0 + RW - 1 < FW - 1 ? fx0 + RW - 1 : FW - 1);
+            const int lead = fxL - fx0, cnt = fxR - fxL + 1;        // clipped-away pixels on the left; pixels inside the frame
+            const unsigned long long fbase = (unsigned long long)a.dyn.frame;
+            unsigned v[PER], msk[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = tid + k * STEM_THREADS, r = i / RPW, j = i - r * RPW;
+                const int fy = qy0 + r - offy;
+                const bool rv = i < RH * RPW && (unsigned)fy < (unsigned)FH && cnt > 0;
+                const unsigned long long G = fbase + (unsigned long long)(rv ? fy : 0) * (unsigned long long)a.dyn.row_stride + 3ull * fxL;
+                const int m = (int)((G - 3ull * lead) & 3ull);
+                const int lo = 3 * lead + m, hi = lo + 3 * cnt;       // the row's valid bytes in LDS
+                int first = lo - 4 * j, last = hi - 4 * j;
+                first = first < 0 ? 0 : first, last = last > 4 ? 4 : last;
+                const bool live = rv && last > first;
+                msk[k] = live ? (0xFFFFFFFFu >> (8 * (4 - last))) & (0xFFFFFFFFu << (8 * first)) : 0u;
+                const unsigned long long addr = live ? G - (unsigned long long)lo + 4ull * j : fbase;  // aligned either way
+                v[k] = *(__attribute__((address_space(1))) const unsigned*)addr;  // global_load_dword (a generic pointer would be a FLAT load)
+                if (j == 0 && i < RH * RPW) rowmis[r] = m;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = tid + k * STEM_THREADS;
+                if (i < RH * RPW) ((unsigned*)reg)[i] = v[k] & msk[k];
+            }
+        }
+        __syncthreads();
+        // -- C: the patch, pixel by pixel, from LDS only
         for (int i = tid; i < prow * STEM_PW; i += STEM_THREADS) {
             const int pr = i / STEM_PW, pc = i - pr * STEM_PW;
-            const int y = iy0 + pr, x = ix0 + pc;
+            const StemRow r = rows[pr];
+            const StemCol q = cols[pc];
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)y < (unsigned)BOX && (unsigned)x < (unsigned)BOX) {
-                int v[3];
-                pyramid_pixel(a.fp, a.dyn, a.tabs, s, y, x, v);
-                o = f32x4{a.tabs->lut[v[0]], a.tabs->lut[v[1]], a.tabs->lut[v[2]], 0.f};
+            if (r.kind && q.kind) {
+                int val[3] = {0, 0, 0};
+                if (r.kind >= 2 && q.kind >= 2) {
+                    const unsigned char* R0 = reg + (r.q0 - qy0) * STEM_REG_PITCH + rowmis[r.q0 - qy0] + 3 * (q.q - qx0);
+                    if (r.kind == 2) {
+                        val[0] = R0[0], val[1] = R0[1], val[2] = R0[2];
+                    } else {
+                        const unsigned char* R1 = reg + (r.q1 - qy0) * STEM_REG_PITCH + rowmis[r.q1 - qy0] + 3 * (q.q - qx0);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            int h0, h1;
+                            if (q.kind == 3) h0 = R0[ch] * q.a0 + R0[3 + ch] * q.a1, h1 = R1[ch] * q.a0 + R1[3 + ch] * q.a1;
+                            else h0 = R0[ch] * 2048, h1 = R1[ch] * 2048;
+                            val[ch] = (((r.b0 * (h0 >> 4)) >> 16) + ((r.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                        }
+                    }
+                }
+                o = f32x4{lut[val[0]], lut[val[1]], lut[val[2]], 0.f};
             }
             ((tx4*)patch)[i] = __builtin_convertvector(o, tx4);
         }
@@ -129,12 +251,14 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 
     // ---- 2. + 3. conv blocks mg, mg + 4, ... of channel half wn; pooling straight from the accumulators -------------------------
     const int col = lane & 31, n = wn * 32 + col;
-    for (int b = mg; b < nblk; b += 4) {
+    for (int b = mg; b < ((a.dbg & 1) ? 0 : nblk); b += 4) {
         // A fragments: this lane's row is conv pixel p = 32 b + (lane & 31) of the tile (rows past the tile read pixel 0: finite values,
         // results unused)
         int p = 32 * b + col;
         if (p >= npix) p = 0;
-        const int cy = p / STEM_CW, cx = p - cy * STEM_CW;
+        const int cy = p / STEM_LW;
+        int cx = p - cy * STEM_LW;
+        if (cx >= STEM_CW) cx = 0;  // the dummy column reads pixel 0 of its row
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -172,25 +296,42 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
                 cur = nxt;
             }
         }
-        // C/D map: column = lane & 31 (channel n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): the 16 conv pixels of this lane
-        const int pbase = 32 * b + 4 * hh;
+        // C/D map: column = lane & 31 (channel n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): this lane holds four groups of four
+        // consecutive M rows, group g at M row 32 b + 4 hh + 8 g = conv pixels (y, x0 .. x0 + 3) with x0 a multiple of 4.  Of the
+        // pooling windows (3 wide, stride 2) that contain them, column window x0 / 2 is complete in the group (x0, x0 + 1, x0 + 2),
+        // window x0 / 2 + 1 gets (x0 + 2, x0 + 3) and window x0 / 2 - 1 gets x0; row-wise conv row y lies in pooled row y >> 1 and, if
+        // even and >= 2, in the one above: at most 6 ds_max_f32 per four values.  Pixels outside the tile / the 184 x 184 conv output
+        // contribute 0, the pooled tile's initial value (ReLU outputs are >= 0).
+        int pp = 32 * b + 4 * hh;
+        int y = pp / STEM_LW, x0 = pp - y * STEM_LW;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int pp = pbase + (r & 3) + 8 * (r >> 2);
-            const int y = pp / STEM_CW, x = pp - y * STEM_CW;  // tile-relative conv pixel (uniform over the 32 lanes of a half)
-            float v = __builtin_fmaxf(acc[r] + bias, 0.f);
-            if constexpr (BF) v = (float)(__bf16)v;           // what the stand-alone conv1 stores (round to nearest even), then pools
-            // inside the tile and inside the 184 x 184 conv output?  (conv row / column 184 is the pool's padding)
-            if (pp < npix && cy0 + y < 2 * 92 && cx0 + x < 2 * 92) {
-                // pooling windows that contain conv row y: pooled row y >> 1 (if the tile owns it) and, for even y >= 2, the one above
-                const int pa = y >> 1, pb = x >> 1;
-                const bool a0 = pa < h, a1 = !(y & 1) && y >= 2, b0 = pb < STEM_TW, b1 = !(x & 1) && x >= 2;
-                float* cell = pooled + (pa * STEM_TW + pb) * 64 + n;
-                if (a0 && b0) __hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (a0 && b1) __hip_atomic_fetch_max(cell - 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (a1 && b0) __hip_atomic_fetch_max(cell - STEM_TW * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (a1 && b1) __hip_atomic_fetch_max(cell - STEM_TW * 64 - 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int g4 = 0; g4 < 4; g4++) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v[e] = __builtin_fmaxf(acc[4 * g4 + e] + bias, 0.f);
+                if constexpr (BF) v[e] = (float)(__bf16)v[e];  // what the stand-alone conv1 stores (round to nearest even), then pools
+                if (x0 + e >= STEM_CW || cx0 + x0 + e >= 2 * 92) v[e] = 0.f;  // the dummy column; conv column 184 (the pool's padding)
             }
+            if (y < nrow && cy0 + y < 2 * 92 && !(a.dbg & 2)) {
+                const float m012 = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]), m23 = __builtin_fmaxf(v[2], v[3]);
+                const int pa = y >> 1, pb = x0 >> 1;
+                const bool up = !(y & 1) && y >= 2;  // also the last row of the pooled row above
+                float* cell = pooled + (pa * STEM_TW + pb) * 64 + n;
+                if (pa < h) {
+                    if (pb < STEM_TW) __hip_atomic_fetch_max(cell, m012, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pb + 1 < STEM_TW) __hip_atomic_fetch_max(cell + 64, m23, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pb >= 1) __hip_atomic_fetch_max(cell - 64, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (up) {
+                    float* above = cell - STEM_TW * 64;
+                    if (pb < STEM_TW) __hip_atomic_fetch_max(above, m012, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pb + 1 < STEM_TW) __hip_atomic_fetch_max(above + 64, m23, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pb >= 1) __hip_atomic_fetch_max(above - 64, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            x0 += 8;  // the lane's next group: 8 M rows on
+            if (x0 >= STEM_LW) x0 -= STEM_LW, y++;
         }
     }
     __syncthreads();
@@ -210,7 +351,7 @@ hipError_t stem_setup()
 {
     hipError_t e;
 #define STEM_ATTR(BF, FR, PR)                                                                                                        \
-    if ((e = hipFuncSetAttribute((const void*)stem_kernel<BF, FR, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_lds<BF>())) != \
+    if ((e = hipFuncSetAttribute((const void*)stem_kernel<BF, FR, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_lds<BF, FR>())) != \
         hipSuccess)                                                                                                                  \
         return e;
     STEM_ATTR(false, false, false) STEM_ATTR(false, false, true) STEM_ATTR(false, true, false) STEM_ATTR(false, true, true)
@@ -219,8 +360,11 @@ hipError_t stem_setup()
     return hipSuccess;
 }
 
-hipError_t launch_stem(const StemArgs& a, hipStream_t st)
+hipError_t launch_stem(const StemArgs& a_in, hipStream_t st)
 {
+    StemArgs a = a_in;
+    static const int dbg = getenv("VNECT_STEM_DBG") ? atoi(getenv("VNECT_STEM_DBG")) : 0;
+    a.dbg = dbg;
     // host-side shape checks: the kernel's indexing assumes exactly these
     if (a.S < 1 || a.groups < 1 || a.groups > STEM_MAXGROUPS || a.row0[0] != 0 || a.row0[a.groups] != 92) return hipErrorInvalidValue;
     for (int g = 0; g < a.groups; g++) {
@@ -230,7 +374,7 @@ hipError_t launch_stem(const StemArgs& a, hipStream_t st)
     if (!a.w || !a.bias || !a.out || (a.from_frame ? (!a.fp || !a.tabs || !a.dyn.frame) : !a.batch)) return hipErrorInvalidValue;
     const dim3 grid(a.S * a.groups * 4), block(STEM_THREADS);
     const bool prof = a.prof != nullptr;
-#define STEM_GO(BF, FR, PR) hipLaunchKernelGGL((stem_kernel<BF, FR, PR>), grid, block, stem_lds<BF>(), st, a)
+#define STEM_GO(BF, FR, PR) hipLaunchKernelGGL((stem_kernel<BF, FR, PR>), grid, block, (stem_lds<BF, FR>()), st, a)
     if (a.bf16) {
         if (a.from_frame) { if (prof) STEM_GO(true, true, true); else STEM_GO(true, true, false); }
         else { if (prof) STEM_GO(true, false, true); else STEM_GO(true, false, false); }

@@ -59,5 +59,8 @@ struct UpTab {  // x8 upsample tables (utils.extract_2d_joints)
 constexpr int STEM_TW = 23;          // pooled columns per tile (92 = 4 x 23)
 constexpr int STEM_MAXH = 5;         // pooled rows per tile at most
 constexpr int STEM_MAXGROUPS = 92;   // row groups per image at most
+constexpr int STEM_PW = 100;         // input-patch row stride in pixels (99 used; even, so a bf16 pixel pair is 16-byte aligned)
+constexpr int STEM_REG_ROWS = 64;    // from-the-frame form: the rectangle of frame bytes a tile's patch is made from, in LDS:
+constexpr int STEM_REG_PITCH = 640;  // at most 64 rows of 640 bytes (3 bytes per pixel + alignment slack)
 
 }  // namespace vnect
