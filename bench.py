@@ -142,8 +142,8 @@ def roofline(tim, nprof, precision, images_frac=1.0):
                   "achieved": round(flops / (exec_ms * 1e-3) / 1e12, 3),
                   "frac": round(flops / (exec_ms * 1e-3) / 1e12 / peak, 4)}
     common = dict(
-        kernel="vnect::conv_stream_kernel<BM,BN,KG,NS,%s,0> (implicit-GEMM conv on MFMA, LDS-DMA ring; %d launches per frame)"
-               % ("false" if precision == "fp32" else "true", launches),
+        kernel="vnect::conv_stream_kernel<BM,BN,KG,NS,%s,0> (implicit-GEMM conv on MFMA, LDS-DMA ring) + vnect::stem_kernel (conv1 + pool1 "
+               "[+ gen_input_batch] on spatial tiles): %d launches per frame" % ("false" if precision == "fp32" else "true", launches),
         launches_per_frame=launches, avg_launch_us=round(conv_ms * 1e3 / launches, 3), first_to_last_wave=first_last,
         kernel_ms_per_frame=round(conv_ms, 4), flops_per_frame=flops,
         algorithmic_per_launch=(flops / launches if precision == "fp32" else BF16_BYTES_PER_FRAME * images_frac / launches),
@@ -396,6 +396,25 @@ def main():
             h2.close()
             clock[0] = base + 100 + args.steps / 30 + 1
 
+    # three independent video streams served by THIS handle (vnect_submit_stream: a filter bank per stream, one weight copy, three
+    # lanes): nothing chains frames of different streams, so they overlap completely.  Beside the headline, never `value`.
+    streams3 = None
+    if not args.no_aux and not args.pyramid:
+        barrier()
+        base = clock[0] + 1000.0
+        s0 = time.perf_counter()
+        for i in range(args.steps):
+            if i >= 3:
+                h.collect_stream()
+            st_ = i % 3
+            h.submit_stream(st_, i % nslots, base + 10 * st_ + i / 30, base + 10 * st_ + i / 30 + 1e-3)
+        for _ in range(min(3, args.steps)):
+            h.collect_stream()
+        torch.cuda.synchronize()
+        streams3 = args.steps / (time.perf_counter() - s0)
+        clock[0] = base + 100 + args.steps / 30
+        h.reset_filters()
+
     nprof = min(max(args.steps // 4, 10), 100)
     tim = None
     if rank == 0 or args.pyramid:  # pyramid: every inference contains the exchange, so every rank must take part
@@ -445,6 +464,7 @@ def main():
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
+            "three_streams_on_one_handle_frames_per_s": None if streams3 is None else round(streams3, 2),
             "roofline": roofline(tim, nprof, args.precision, frac_images),
         }
     h.close()

@@ -20,8 +20,9 @@
 extern "C" {
 #endif
 
-#define VNECT_ABI_VERSION 2
+#define VNECT_ABI_VERSION 3
 #define VNECT_MAX_SCALES 8
+#define VNECT_MAX_STREAMS 4 /* independent video streams one handle can serve (vnect_submit_stream) */
 #define VNECT_BOX 368      /* src/estimator.py:19 box_size   */
 #define VNECT_HM 46        /* box_size / hm_factor (:21)     */
 #define VNECT_JOINTS 21    /* src/estimator.py:23 joints_sum */
@@ -129,6 +130,17 @@ int vnect_infer_resident(vnect_handle* h, int slot, double t2d, double t3d, doub
  * At most max(lanes, 2) frames may be in flight (one lane: the second frame queues behind the first on its stream). */
 int vnect_submit_resident(vnect_handle* h, int slot, double t2d, double t3d);
 int vnect_collect(vnect_handle* h, double* joints_2d, float* joints_3d);
+/* Several independent video streams on ONE handle (one weight copy, `lanes` activation arenas): the reference runs one
+ * VNectEstimator -- one set of 42 + 63 OneEuro filters, src/estimator.py:46-52 -- per video, each in a process of its own
+ * (run_estimator_ps.py:120-129); here stream s (0 .. VNECT_MAX_STREAMS-1) is a filter bank + its timestamps on the device, and
+ * vnect_submit_stream(h, s, ...) is that stream's __call__.  Frames of DIFFERENT streams have no dependency at all, so with
+ * lanes = 2 / 3 they overlap completely (frames of one stream still chain through their filters, exactly as vnect_submit_resident
+ * -- which is stream 0 -- does).  Results come back in submission order; vnect_collect_stream also says whose they are.  Each
+ * stream's results are bit-identical to a handle of its own fed the same frames. */
+int vnect_submit_stream(vnect_handle* h, int stream, int slot, double t2d, double t3d);
+int vnect_collect_stream(vnect_handle* h, int32_t* stream_out, double* joints_2d, float* joints_3d);
+/* New filters for ONE stream (vnect_reset_filters resets all of them). */
+int vnect_reset_filters_stream(vnect_handle* h, int stream);
 
 /* Replaces VNectEstimator.joint_filter(joints, dim) (src/estimator.py:83-95) on its own: the handle's 2-D (dim 2: 21x2)
  * or 3-D (dim 3: 21x3) OneEuro bank applied to caller-supplied joints at timestamp t (the reference reads time.time() once

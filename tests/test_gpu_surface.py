@@ -260,3 +260,63 @@ def test_no_exception_crosses_the_abi(weights):
     out = h.forward(np.zeros((1, 368, 368, 3), np.float32))
     assert np.all(np.isfinite(out))
     h.close()
+
+
+# ------------------------------------------------------------------------------------------ several streams on one handle
+def test_streams_on_one_handle_equal_handles_of_their_own(weights):
+    """vnect_submit_stream: three independent videos (different frames, crop sizes, timestamps, irregular interleaving) served by
+    ONE handle with three lanes -- one weight copy, a filter bank per stream -- must return, for every frame of every stream,
+    exactly what a handle of its own returns for that video frame by frame (the reference's model: one VNectEstimator per video,
+    run_estimator_ps.py:120-129).  Frames of different streams are in flight together; only frames of one stream chain."""
+    from vnect_amd import _native
+    from tests import helpers
+    scales = [1.0, 0.8, 0.6]
+
+    def make(**kw):
+        h = _native.Handle(scales, num_frame_slots=8, **kw)
+        h.set_weights(weights)
+        h.finalize()
+        return h
+    shapes = [(368, 368), (240, 320), (368, 200)]
+    nfr = 5
+    vids = [[helpers.synth_frame(7000 + 100 * s + k, *shapes[s], smooth=True) for k in range(nfr)] for s in range(3)]
+    times = [[T0 + 10 * s + 0.04 * k + 0.003 * ((k * (s + 2)) % 3) for k in range(nfr)] for s in range(3)]
+    want = []
+    for s in range(3):                      # the reference's way: an estimator per video, one frame at a time
+        h = make()
+        want.append([h.infer(vids[s][k], times[s][k], times[s][k] + 0.001) for k in range(nfr)])
+        h.close()
+    shared = make(lanes=3)
+    order = [0, 1, 2, 2, 0, 1, 1, 1, 0, 2, 0, 2, 1, 0, 2]   # 5 frames of each stream, irregularly interleaved
+    nxt, inflight, got = [0, 0, 0], [], [[], [], []]
+    for i, s in enumerate(order):
+        if len(inflight) == 3:
+            rs, j2, j3 = shared.collect_stream()
+            assert rs == inflight.pop(0)
+            got[rs].append((j2, j3))
+        k = nxt[s]
+        nxt[s] += 1
+        slot = i % 8
+        shared.upload_frame(slot, vids[s][k])
+        shared.submit_stream(s, slot, times[s][k], times[s][k] + 0.001)
+        inflight.append(s)
+    while inflight:
+        rs, j2, j3 = shared.collect_stream()
+        assert rs == inflight.pop(0)
+        got[rs].append((j2, j3))
+    for s in range(3):
+        assert len(got[s]) == nfr
+        for k in range(nfr):
+            assert np.array_equal(got[s][k][0], want[s][k][0]) and np.array_equal(got[s][k][1], want[s][k][1]), (s, k)
+    # a stream's filters restart on their own; a bad stream index and a repeated timestamp are refused before any state changes
+    shared.reset_filters_stream(1)
+    shared.upload_frame(0, vids[1][0])
+    shared.submit_stream(1, 0, times[1][0], times[1][0] + 0.001)     # t earlier than stream 1's last frame: fine after the reset
+    rs, j2, j3 = shared.collect_stream()
+    assert rs == 1 and np.array_equal(j2, want[1][0][0]) and np.array_equal(j3, want[1][0][1])
+    with pytest.raises(_native.VnectError):
+        shared.submit_stream(4, 0, 1.0, 1.0)
+    with pytest.raises(_native.VnectError) as e:
+        shared.submit_stream(0, 0, times[0][-1], times[0][-1] + 0.001)
+    assert e.value.code == _native.E_TIMESTAMP
+    shared.close()

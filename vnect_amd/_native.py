@@ -15,7 +15,8 @@ _lib = None
 
 MAX_SCALES = 8
 OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM, E_TIMEORDER, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
-ABI_VERSION = 2
+ABI_VERSION = 3
+MAX_STREAMS = 4
 XCHG_RCCL, XCHG_P2P = 0, 1
 FP32, BF16 = 0, 1
 
@@ -65,6 +66,9 @@ SYMBOLS = {
     "vnect_infer_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, _f64p, _f32p]),
     "vnect_submit_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
     "vnect_collect": (C.c_int, [_H, _f64p, _f32p]),
+    "vnect_submit_stream": (C.c_int, [_H, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "vnect_collect_stream": (C.c_int, [_H, _i32p, _f64p, _f32p]),
+    "vnect_reset_filters_stream": (C.c_int, [_H, C.c_int]),
     "vnect_joint_filter": (C.c_int, [_H, C.c_int, _f64p, C.c_int, C.c_double, _f64p]),
     "vnect_reset_filters": (C.c_int, [_H]),
     "vnect_read_activation": (C.c_int, [_H, C.c_char_p, _f32p, C.c_int64, _i32p]),
@@ -231,6 +235,20 @@ class Handle:
             self._ck(rc)
         return j2.copy(), j3.copy()
 
+    def submit_stream(self, stream, slot, t2d, t3d):
+        """One frame of video stream `stream` (its own filter bank and timestamps on this handle): frames of different streams
+        overlap on the handle's lanes with no dependency between them."""
+        self._ck(lib().vnect_submit_stream(self._h, stream, slot, t2d, t3d))
+
+    def collect_stream(self):
+        """(stream, joints_2d, joints_3d) of the oldest frame in flight."""
+        j2, j3, p2, p3, _, _ = self._results()
+        s = C.c_int32(-1)
+        rc = lib().vnect_collect_stream(self._h, C.byref(s), p2, p3)
+        if rc:
+            self._ck(rc)
+        return s.value, j2.copy(), j3.copy()
+
     @staticmethod
     def comm_unique_id():
         buf = (C.c_char * 128)()
@@ -264,6 +282,9 @@ class Handle:
             raise ValueError("p2p_init needs one 128-byte blob per rank")
         buf = (C.c_char * len(raw)).from_buffer_copy(raw)
         self._ck(lib().vnect_comm_p2p_init(self._h, rank, nranks, buf))
+
+    def reset_filters_stream(self, stream):
+        self._ck(lib().vnect_reset_filters_stream(self._h, stream))
 
     def reset_filters(self):
         self._ck(lib().vnect_reset_filters(self._h))

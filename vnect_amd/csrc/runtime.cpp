@@ -110,15 +110,20 @@ struct vnect_handle {
     ArgPartial* d_part = nullptr;
     unsigned* d_ticket = nullptr;  // post_kernel's arrival counter (zero between launches)
     bool post_merged = true;       // merge + arg-max + joints as ONE launch (post_kernel); false: two launches (VNECT_NO_POST_MERGE=1)
-    FilterBank* d_fb = nullptr;
+    FilterBank* d_fb = nullptr;    // [VNECT_MAX_STREAMS]
     double* h_filt = nullptr;      // pinned, device-mapped: vnect_joint_filter's values in ([0, 64)) and out ([64, 128))
     double* h_filt_dev = nullptr;
     JointsOut* h_out[RING] = {};   // pinned, device-mapped: joints_kernel writes a frame's results straight into its ring slot
     JointsOut* h_out_dev[RING] = {};  // the same slots as the device addresses them
     hipEvent_t done[RING] = {};
     unsigned long long seq_submit = 0, seq_collect = 0;
-    bool have2 = false, have3 = false;
-    double last2 = 0, last3 = 0;
+    // per video stream (vnect_submit_stream; stream 0 is what every other entry point uses): d_fb[stream] on the device, and here
+    // the host's copy of the last timestamps, the sequence number of the stream's last frame and the lane it ran on
+    bool have2[VNECT_MAX_STREAMS] = {}, have3[VNECT_MAX_STREAMS] = {};
+    double last2[VNECT_MAX_STREAMS] = {}, last3[VNECT_MAX_STREAMS] = {};
+    long long stream_seq[VNECT_MAX_STREAMS] = {-1, -1, -1, -1};
+    vnect_handle* stream_lane[VNECT_MAX_STREAMS] = {};
+    int ring_stream[RING] = {};
     // cached squarify table
     int sq_H = -1, sq_W = -1;
     FrameParams sq_cache{};
@@ -892,18 +897,18 @@ int run_argmax(vnect_handle* h)
 }
 
 // filters + read-off; results go straight to `out` (a device-mapped pinned host slot)
-int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
+int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out, int stream = 0)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, launch_joints(h->d_part, maps, h->d_mtabs, h->S, h->d_fb, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
+    HIPCK(h, launch_joints(h->d_part, maps, h->d_mtabs, h->S, h->d_fb + stream, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
     return VNECT_OK;
 }
 
 // both in one launch (post.hip: post_kernel): takes the frame's arguments by value, so it runs behind the graph, not inside it
-int run_post(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
+int run_post(vnect_handle* h, const FrameDyn& dyn, JointsOut* out, int stream = 0)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, launch_post(maps, h->d_mtabs, h->S, h->d_up, h->d_part, h->d_ticket, h->d_fb, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
+    HIPCK(h, launch_post(maps, h->d_mtabs, h->S, h->d_up, h->d_part, h->d_ticket, h->d_fb + stream, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
     return VNECT_OK;
 }
 
@@ -913,25 +918,25 @@ int run_post(vnect_handle* h, const FrameDyn& dyn, JointsOut* out)
 //                 (OneEuroFilter.py:19-23) -> VNECT_E_TIMEORDER.
 // Nothing is committed here: the reference would leave half-updated filters behind its exception, this path rejects the call
 // before any state changes, and the host-side copy of the last timestamps moves only after the frame has been enqueued.
-int check_time(vnect_handle* h, double t2d, double t3d)
+int check_time(vnect_handle* h, double t2d, double t3d, int s = 0)
 {
-    if (h->have2 && h->last2 != 0.0 && t2d != 0.0) {
-        if (t2d == h->last2) return fail(h, VNECT_E_TIMESTAMP, "t2d equals the previous 2-D filter timestamp");
-        if (t2d < h->last2) return fail(h, VNECT_E_TIMEORDER, "t2d is earlier than the previous 2-D filter timestamp");
+    if (h->have2[s] && h->last2[s] != 0.0 && t2d != 0.0) {
+        if (t2d == h->last2[s]) return fail(h, VNECT_E_TIMESTAMP, "t2d equals the previous 2-D filter timestamp");
+        if (t2d < h->last2[s]) return fail(h, VNECT_E_TIMEORDER, "t2d is earlier than the previous 2-D filter timestamp");
     }
-    if (h->have3 && h->last3 != 0.0 && t3d != 0.0) {
-        if (t3d == h->last3) return fail(h, VNECT_E_TIMESTAMP, "t3d equals the previous 3-D filter timestamp");
-        if (t3d < h->last3) return fail(h, VNECT_E_TIMEORDER, "t3d is earlier than the previous 3-D filter timestamp");
+    if (h->have3[s] && h->last3[s] != 0.0 && t3d != 0.0) {
+        if (t3d == h->last3[s]) return fail(h, VNECT_E_TIMESTAMP, "t3d equals the previous 3-D filter timestamp");
+        if (t3d < h->last3[s]) return fail(h, VNECT_E_TIMEORDER, "t3d is earlier than the previous 3-D filter timestamp");
     }
     return VNECT_OK;
 }
 // `self.__lasttime = timestamp` runs on every call, also with timestamp 0.0 / None
-void commit_time(vnect_handle* h, double t2d, double t3d)
+void commit_time(vnect_handle* h, double t2d, double t3d, int s = 0)
 {
-    h->have2 = h->have3 = true, h->last2 = t2d, h->last3 = t3d;
+    h->have2[s] = h->have3[s] = true, h->last2[s] = t2d, h->last3[s] = t3d;
 }
 
-int reset_filters_impl(vnect_handle* h)
+int reset_filters_impl(vnect_handle* h, int stream = -1)  // -1: every stream
 {
     std::vector<FilterBank> fb(1);
     memset(fb.data(), 0, sizeof(FilterBank));
@@ -945,9 +950,12 @@ int reset_filters_impl(vnect_handle* h)
             f.freq = 30, f.mincutoff = 0.8, f.beta = 0.4, f.dcutoff = 0.4;
         }
     }
-    HIPCK(h, hipMemcpyAsync(h->d_fb, fb.data(), sizeof(FilterBank), hipMemcpyHostToDevice, h->st));
+    for (int s = 0; s < VNECT_MAX_STREAMS; s++) {
+        if (stream >= 0 && s != stream) continue;
+        HIPCK(h, hipMemcpyAsync(h->d_fb + s, fb.data(), sizeof(FilterBank), hipMemcpyHostToDevice, h->st));
+        h->have2[s] = h->have3[s] = false;
+    }
     HIPCK(h, hipStreamSynchronize(h->st));
-    h->have2 = h->have3 = false;
     return VNECT_OK;
 }
 
@@ -1136,8 +1144,10 @@ int build_twins(vnect_handle* h)
 }
 
 // enqueue one frame from a resident slot; results land in h_out[ring]
-int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_out)
+int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_out, int stream = 0)
 {
+    if (stream < 0 || stream >= VNECT_MAX_STREAMS) return fail(h, VNECT_E_ARG, "stream out of range");
+    if (stream != 0 && h->sharded) return fail(h, VNECT_E_ARG, "a pyramid-sharded handle serves one stream");
     if (slot < 0 || slot >= (int)h->slots.size() || h->slots[slot].H == 0)
         return fail(h, VNECT_E_ARG, "frame slot empty or out of range");
     const unsigned long long max_in_flight = h->twins.empty() ? 2 : h->twins.size() + 1;  // one lane: two frames queue on its stream
@@ -1148,7 +1158,7 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     FrameParams fp;
     int rc = squarify_params(h, si.H, si.W, &fp);
     if (rc) return rc;
-    rc = check_time(h, t2d, t3d);
+    rc = check_time(h, t2d, t3d, stream);
     if (rc) return rc;
     const int ring = (int)(h->seq_submit % RING);
     FrameDyn dyn{};
@@ -1191,13 +1201,16 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
         if (!L->post_merged && (rc = run_argmax(L))) return fail(h, rc, L->err);
     }
     if (g_roctx.pop) g_roctx.pop(), g_roctx.push(L->post_merged ? "vnect:merge+argmax+filters+readoff" : "vnect:filters+readoff");  // r_net's pop now closes this range
-    if (h->seq_submit > 0 && h->last_lane && h->last_lane != L)  // the filters are a chain: frame k's state feeds frame k+1
-        HIPCK(h, hipStreamWaitEvent(L->st, h->done[(h->seq_submit - 1) % RING], 0));
+    // the filters are a chain WITHIN a video stream: this frame's post-processing waits for the stream's previous frame if that one
+    // ran on another lane and may still be in flight (frames of other streams are no concern of it)
+    if (h->stream_seq[stream] >= (long long)h->seq_collect && h->stream_lane[stream] && h->stream_lane[stream] != L)
+        HIPCK(h, hipStreamWaitEvent(L->st, h->done[h->stream_seq[stream] % RING], 0));
     // writes the ring slot in pinned host memory
-    if ((rc = L->post_merged ? run_post(L, dyn, h->h_out_dev[ring]) : run_joints(L, dyn, h->h_out_dev[ring]))) return fail(h, rc, L->err);
+    if ((rc = L->post_merged ? run_post(L, dyn, h->h_out_dev[ring], stream) : run_joints(L, dyn, h->h_out_dev[ring], stream))) return fail(h, rc, L->err);
     if (timed) HIPCK(h, hipEventRecord(h->ev[3], L->st));
     HIPCK(h, hipEventRecord(h->done[ring], L->st));
-    commit_time(h, t2d, t3d);  // only now: every launch of the frame has been accepted
+    commit_time(h, t2d, t3d, stream);  // only now: every launch of the frame has been accepted
+    h->stream_seq[stream] = (long long)h->seq_submit, h->stream_lane[stream] = L, h->ring_stream[ring] = stream;
     h->last_lane = L;
     L->lane_seq = (long long)h->seq_submit;
     h->slots[slot].last_use = (long long)h->seq_submit;
@@ -1206,7 +1219,7 @@ int enqueue_frame(vnect_handle* h, int slot, double t2d, double t3d, int* ring_o
     return VNECT_OK;
 }
 
-int collect_impl(vnect_handle* h, double* j2, float* j3)
+int collect_impl(vnect_handle* h, double* j2, float* j3, int32_t* stream_out = nullptr)
 {
     if (h->seq_collect == h->seq_submit) return fail(h, VNECT_E_STATE, "nothing in flight");
     const int ring = (int)(h->seq_collect % RING);
@@ -1226,6 +1239,7 @@ int collect_impl(vnect_handle* h, double* j2, float* j3)
     }
     if (j2) memcpy(j2, h->h_out[ring]->j2d, sizeof(double) * NJ * 2);
     if (j3) memcpy(j3, h->h_out[ring]->j3d, sizeof(float) * NJ * 3);
+    if (stream_out) *stream_out = h->ring_stream[ring];
     if (h->profiling) {
         float frame_ms = 0;
         hipEventElapsedTime(&frame_ms, h->ev[0], h->ev[3]);
@@ -1377,7 +1391,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         if ((rc = dev_alloc(h, &h->d_ticket, 4))) return rc;
         HIPCK(h, hipMemset(h->d_ticket, 0, 4 * sizeof(unsigned)));
         h->post_merged = getenv("VNECT_NO_POST_MERGE") == nullptr;
-        if (!pre && (rc = dev_alloc(h, &h->d_fb, 1))) return rc;
+        if (!pre && (rc = dev_alloc(h, &h->d_fb, VNECT_MAX_STREAMS))) return rc;
         if ((rc = dev_alloc(h, &h->in3, (size_t)(pre ? h->Snet : VNECT_MAX_SCALES) * BOX * BOX * 3))) return rc;
         if (!pre && (rc = dev_alloc(h, &h->gather, (size_t)VNECT_MAX_SCALES * HM * HM * MAPC))) return rc;
         for (int i = 0; i < RING; i++) {
@@ -1634,6 +1648,38 @@ int vnect_submit_resident(vnect_handle* h, int slot, double t2d, double t3d)
     });
 }
 
+int vnect_submit_stream(vnect_handle* h, int stream, int slot, double t2d, double t3d)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        if (!h->finalized) return fail(h, VNECT_E_STATE, "inference before vnect_finalize");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int ring;
+        return enqueue_frame(h, slot, t2d, t3d, &ring, stream);
+    });
+}
+
+int vnect_collect_stream(vnect_handle* h, int32_t* stream_out, double* j2, float* j3)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        return collect_impl(h, j2, j3, stream_out);
+    });
+}
+
+int vnect_reset_filters_stream(vnect_handle* h, int stream)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h) return VNECT_E_ARG;
+        if (stream < 0 || stream >= VNECT_MAX_STREAMS) return fail(h, VNECT_E_ARG, "stream out of range");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        if (h->pre_only) return fail(h, VNECT_E_STATE, "vnect_reset_filters_stream on a preprocess_only handle (it has no filter bank)");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        return reset_filters_impl(h, stream);
+    });
+}
+
 int vnect_collect(vnect_handle* h, double* j2, float* j3)
 {
     return guarded(&h, [&]() -> int {
@@ -1677,8 +1723,8 @@ int vnect_joint_filter(vnect_handle* h, int dim, const double* joints_in, int va
         if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
         HIPCK(h, hipSetDevice(h->cfg.device));
         // the timestamp rules of check_time, for the one bank this call advances
-        const bool have = dim == 2 ? h->have2 : h->have3;
-        const double last = dim == 2 ? h->last2 : h->last3;
+        const bool have = dim == 2 ? h->have2[0] : h->have3[0];   // (stream 0: the bank vnect_infer advances)
+        const double last = dim == 2 ? h->last2[0] : h->last3[0];
         if (have && last != 0.0 && t != 0.0) {
             if (t == last) return fail(h, VNECT_E_TIMESTAMP, "timestamp equals the previous one of this filter bank");
             if (t < last) return fail(h, VNECT_E_TIMEORDER, "timestamp is earlier than the previous one of this filter bank");
@@ -1687,8 +1733,8 @@ int vnect_joint_filter(vnect_handle* h, int dim, const double* joints_in, int va
         memcpy(h->h_filt, joints_in, sizeof(double) * n);
         HIPCK(h, launch_filter(h->d_fb, dim, values_are_f32 != 0, h->cfg.numpy_promotion, t, h->h_filt_dev, h->h_filt_dev + 64, h->st));
         HIPCK(h, hipStreamSynchronize(h->st));
-        if (dim == 2) h->have2 = true, h->last2 = t;
-        else h->have3 = true, h->last3 = t;
+        if (dim == 2) h->have2[0] = true, h->last2[0] = t;
+        else h->have3[0] = true, h->last3[0] = t;
         memcpy(joints_out, h->h_filt + 64, sizeof(double) * n);
         return VNECT_OK;
     });
