@@ -42,7 +42,11 @@ enum {
     VNECT_E_INTERNAL = -8   /* host allocation failure or an internal C++ exception, caught at the boundary */
 };
 
-enum { VNECT_FP32 = 0, VNECT_BF16 = 1 };
+enum { VNECT_FP32 = 0,        /* fp32 tensors, v_mfma_f32_32x32x2_f32 (BASELINE.json configs[1])                                      */
+       VNECT_BF16 = 1,        /* bf16 tensors and weights, fp32 accumulate (configs[2])                                               */
+       VNECT_FP32_SPLIT = 2   /* fp32 tensors, fp32 accumulate; the PRODUCTS of the 64x64-tile layers run on the bf16 matrix pipe as
+                                 exact three-way splits (x = xh + xm + xl, 6 of the 9 piece products; conv.hip, X3): fp32-class
+                                 results -- gated like VNECT_FP32 -- at 2.7x the matrix rate of the fp32 instruction                  */ };
 
 typedef struct vnect_handle vnect_handle;
 
@@ -51,7 +55,7 @@ typedef struct vnect_config {
     int32_t device;                   /* HIP device ordinal                                       */
     int32_t num_scales;               /* len(self.scales), src/estimator.py:32                    */
     double scales[VNECT_MAX_SCALES];  /* each in (0, 1]                                           */
-    int32_t precision;                /* VNECT_FP32 | VNECT_BF16                                  */
+    int32_t precision;                /* VNECT_FP32 | VNECT_BF16 | VNECT_FP32_SPLIT               */
     int32_t paper_res2c;              /* 0 = reference wiring src/vnect_model.py:56 (default)     */
     int32_t use_graph;                /* 0 = eager launches; 1 = replay the frame as one hipGraph;
                                          2 = auto: eager for a frame submitted while none is in flight

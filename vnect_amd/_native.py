@@ -18,7 +18,7 @@ OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM, E_TIMEORDER, E_INTER
 ABI_VERSION = 3
 MAX_STREAMS = 4
 XCHG_RCCL, XCHG_P2P = 0, 1
-FP32, BF16 = 0, 1
+FP32, BF16, FP32_SPLIT = 0, 1, 2
 
 
 class VnectError(RuntimeError):

@@ -257,18 +257,29 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
 // The producers land the run(s) as they lie in memory (three DMA instructions per chunk instead of eight), and a consumer lane
 // reads its fragment at pixel slot 2 row + 2 q + h of the run.  The K order is unchanged; the 16 MFMAs per chunk become 12: channel 3
 // of the NHWC4 input is the zero padding channel (zero weights), so the e = 3 MFMA of every group adds exact zeros.
-template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false>
+// X3 (fp32 activations, VNECT_FP32_SPLIT): the split-product form.  The fp32 matrix instruction runs at 1 / 16 of the bf16 one's rate on
+// this chip (157 vs 2 500 TFLOP/s), so an fp32 product is cheaper as SIX bf16 products: every fp32 operand is the exact sum of three
+// bf16 pieces (8 + 8 + 8 significand bits), x = xh + xm + xl, and x w = xh wh + xh wm + xm wh + xh wl + xl wh + xm wm + (three terms
+// below 2^-23 |x w|, dropped), each bf16 x bf16 product exact in fp32 and all of them accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+// 6 x 32 cycles per 16 K-elements against 8 x 64 for v_mfma_f32_32x32x2_f32.  The A operand stays what it is (fp32 tensors, the same
+// LDS image); a consumer lane splits its 8 values per K step in registers (mask, subtract, mask, subtract: exact).  The weights are
+// split offline (hostplan.h: pack_split3) and land as three 64-byte planes per row and chunk -- 20 KiB per stage instead of 16, so the
+// ring has 4 stages in the same 80 KB.  Results differ from the fp32 instruction's in the last bits only (summation order, the dropped
+// terms); the parity gates are the fp32 path's.
+template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false, bool X3 = false>
 __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
     constexpr bool TAIL = FUSE == 1, BONE = FUSE == 2;
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
+    static_assert(!X3 || (BM == 64 && BN == 64 && KG == 1 && !BF && !SPAN && FUSE != 2 && PROF < 2), "split-product form: 64x64 tiles of fp32 layers");
     static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1), "the fused forms are built for one 64x64 tile per workgroup");
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
     constexpr int ARB = BM / 32, BRB = BN / 32, WMN = ARB * BRB;  // 32-row blocks of A and B; accumulators per K group
-    constexpr int ROWS = BM + BN, SUB = ROWS * 32;               // one K group's image: ROWS x 128 B
-    constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : KG * ROWS / 32;  // floats per ring stage; LDS-DMA instructions per producer wave per step
+    constexpr int BROWF = X3 ? 48 : 32;                          // floats per B row and chunk (X3: three 64-byte planes, plane-major in the stage)
+    constexpr int ROWS = BM + BN, SUB = BM * 32 + BN * BROWF;    // one K group's image: BM A rows x 128 B, then the B rows
+    constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : (X3 ? ARB + 3 : KG * ROWS / 32);  // floats per ring stage; LDS-DMA instructions per producer wave per step
     constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x 4 KiB, then WMN*(KG-1) flags
     constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
     static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         const srd_t srdA = make_srd((const char*)p.in - p.tap_bias), srdB = make_srd(p.w);
         const int srow = tid >> 3;
         const int unit = (tid & 7) ^ ((tid >> 4) & 7);  // source unit for LDS slot (row 32i + srow, unit tid&7)
-        unsigned a_vo[ARB], a_mask[ARB], a_cur[ARB], b_vo[BRB];
+        unsigned a_vo[ARB], a_mask[ARB], a_cur[ARB], b_vo[BRB], b_vo3[3] = {0, 0, 0};
         unsigned soA = 0, soB = 0;
         int tb = 0;  // first tap-table entry of the item's phase (indexing the argument block directly keeps it in constant memory)
         int tap = 0, cc = 0, rem = 0, jn = 0;
@@ -445,9 +456,18 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                     }
                 }
             }
+            if constexpr (X3) {
+                // plane pl of this wave's 16 weight rows: LDS slot (row 16 wave + (lane >> 2), 16-byte unit lane & 3) takes source unit
+                // (lane & 3) ^ ((row >> 2) & 3) -- the XOR that spreads a fragment read's 16 rows x 64 B over all banks
+                const int brow = wave * 16 + (lane >> 2), bun = (lane & 3) ^ ((brow >> 2) & 3);
 #pragma unroll
-            for (int i = 0; i < BRB; i++) b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
-            soB = (unsigned)__builtin_amdgcn_readfirstlane((int)((it.phase * p.w_phase_stride + (long long)it.c0 * (EPR * KG)) * ESZ));
+                for (int pl = 0; pl < 3; pl++) b_vo3[pl] = (unsigned)((it.n0 + brow) * (p.K / 32) * 192 + pl * 64 + bun * 16);
+                soB = (unsigned)__builtin_amdgcn_readfirstlane(it.c0 * 192);
+            } else {
+#pragma unroll
+                for (int i = 0; i < BRB; i++) b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
+                soB = (unsigned)__builtin_amdgcn_readfirstlane((int)((it.phase * p.w_phase_stride + (long long)it.c0 * (EPR * KG)) * ESZ));
+            }
             tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = __builtin_amdgcn_readfirstlane(it.c0 - tap * h.cpt);
             rem = __builtin_amdgcn_readfirstlane(it.cnt);
             set_tap(tap);
@@ -461,15 +481,20 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             for (int k = 0; k < KG; k++) {  // K group k: the k-th 128-byte run of the step, landed in its own image
 #pragma unroll
                 for (int i = 0; i < (SPAN ? 1 : ARB); i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
+                if constexpr (X3) {
 #pragma unroll
-                for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], uB + k * 128);
+                    for (int pl = 0; pl < 3; pl++) bload_lds(srdB, sb + BM * 32 + pl * (BN * 16), b_vo3[pl], uB);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], uB + k * 128);
+                }
             }
             rem = __builtin_amdgcn_readfirstlane(rem - 1);
             if (rem == 0) {
                 jn = __builtin_amdgcn_readfirstlane(jn + 1);
                 if (jn < my_n) begin_item(jn);
             } else {
-                soA += 128 * KG, soB += 128 * KG;
+                soA += 128 * KG, soB += X3 ? 192 : 128 * KG;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
             }
         };
@@ -643,6 +668,70 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         stage = nstage;
     };
 
+    // ---- X3: the split-product K loop (see the kernel's head comment).  A chunk = two K steps of 16; the operands of a K step are
+    // the lane's 8 fp32 activations (two 16-byte units of the A row) and 8 bf16 of each weight plane (one unit of the plane's row).
+    // Always one K step ahead: while step 0 multiplies, step 1's operands are read from the same stage; while step 1 multiplies, step
+    // 0 of the NEXT chunk (visible since this chunk's barrier) is read.
+    struct Kx {
+        f32x4 a0, a1, b[3];
+    };
+    Kx R0 = {}, R1 = {};
+    int foA3[2][2] = {{0, 0}, {0, 0}}, foB3[2] = {0, 0};
+    if constexpr (X3) {
+        const int sw = (lane >> 1) & 7, swb = (lane >> 2) & 3;  // (row >> 1) & 7 of the A row, (row >> 2) & 3 of the B row: rows are 32 wm / wn + (lane & 31)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; j2++) foA3[s2][j2] = (wm * 32 + (lane & 31)) * 32 + (((4 * s2 + 2 * (lane >> 5) + j2) ^ sw) * 4);
+            foB3[s2] = BM * 32 + (wn * 32 + (lane & 31)) * 16 + (((2 * s2 + (lane >> 5)) ^ swb) * 4);
+        }
+    }
+    auto ldx = [&](Kx& R, int stg, int s2) __attribute__((always_inline)) {
+        const float* sb = smem + stg * STAGE;
+        R.a0 = *(const f32x4*)(sb + foA3[s2][0]), R.a1 = *(const f32x4*)(sb + foA3[s2][1]);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) R.b[pl] = *(const f32x4*)(sb + foB3[s2] + pl * (BN * 16));
+    };
+    auto mmx = [&](const Kx& R) __attribute__((always_inline)) {
+        // x = hi + mid + lo by truncation (exact): hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of x - hi - mid
+        unsigned xb[8], hb[8], mb[8], lb[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float x = e < 4 ? R.a0[e & 3] : R.a1[e & 3];
+            xb[e] = __builtin_bit_cast(unsigned, x);
+            const float r1 = x - __builtin_bit_cast(float, xb[e] & 0xffff0000u);
+            hb[e] = xb[e];
+            mb[e] = __builtin_bit_cast(unsigned, r1);
+            lb[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb[e] & 0xffff0000u));
+        }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 H, Mi, L;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {  // two bf16 per dword: the high halves of elements 2 q + 1 and 2 q
+            H[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);
+            Mi[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
+            L[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
+        }
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, H), am = __builtin_bit_cast(bf16x8, Mi), al = __builtin_bit_cast(bf16x8, L);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, R.b[0]), wmid = __builtin_bit_cast(bf16x8, R.b[1]), wl = __builtin_bit_cast(bf16x8, R.b[2]);
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wmid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wmid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+    };
+    auto step3 = [&]() __attribute__((always_inline)) {
+        const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        __builtin_amdgcn_s_barrier();  // chunk g+1 visible; every consumer is past chunk g-1
+        ldx(R1, stage, 1);
+        mmx(R0);
+        ldx(R0, nstage, 0);
+        mmx(R1);
+        stage = nstage;
+    };
+
     struct Cons {
         const float *bias, *scale, *shift, *resid;
         float *out, *out2, *ws;
@@ -665,7 +754,8 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     __builtin_amdgcn_s_barrier();  // chunk 0 visible
     if (pstamp) prof[11] = __builtin_amdgcn_s_memrealtime();
     if constexpr (SPAN) set_span(decode(0).m0);
-    rall(0, F0);
+    if constexpr (X3) ldx(R0, 0, 0);
+    else rall(0, F0);
     for (int j = 0; j < my_n; j++) {
         const Item it = decode(j);
         if constexpr (SPAN) {
@@ -711,11 +801,15 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        for (int t = 0; t < it.cnt; t += 2) {
-            step(F0, F1);
-            if (t + 1 < it.cnt) step(F1, F0);
+        if constexpr (X3) {
+            for (int t = 0; t < it.cnt; t++) step3();
+        } else {
+            for (int t = 0; t < it.cnt; t += 2) {
+                step(F0, F1);
+                if (t + 1 < it.cnt) step(F1, F0);
+            }
+            if (it.cnt & 1) F0 = F1;  // odd chunk count: the fragments of the next item's first chunk sit in F1
         }
-        if (it.cnt & 1) F0 = F1;  // odd chunk count: the fragments of the next item's first chunk sit in F1
         if (pstamp && j == 0) prof[20] = __builtin_amdgcn_s_memrealtime();  // first item: K loop done
         if constexpr (KG > 1) {
             // K groups 1.. hand their accumulators to group 0 through LDS (lane-linear 16-byte slots: conflict-free) and go
@@ -897,6 +991,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 
 template <int BM, int BN, int KG, int NS>
 constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
+constexpr int X3_NS = 4;  // split-product form: 4 stages of 64 x 128 B + 64 x 192 B = 20 KiB (the same 80 KB as 5 x 16 KiB)
+constexpr size_t x3_lds() { return (size_t)X3_NS * (64 * 32 + 64 * 48) * 4; }
 
 template <int BM, int BN, int KG, int NS>
 static hipError_t launch_stream(ConvArgs a, hipStream_t st)
@@ -919,6 +1015,21 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     const int prof = a.prof ? (detail ? 2 : 1) : 0;
 #define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a)
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
+        if (a.x3) {  // split-product form (plain or with the tail GEMM behind it); start / end stamps at most
+            if (a.bf16 || a.pixmode || a.nphase != 1 || a.bone || a.K % 32) return hipErrorInvalidValue;
+            if (a.tail_n > 0 && (a.items > maxwg || a.ksplit != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias))
+                return hipErrorInvalidValue;
+#define LAUNCH_X3(PR, FU) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, PR, FU, false, true>), grid, dim3(512), x3_lds(), st, a)
+            if (a.tail_n > 0) {
+                if (prof == 0) LAUNCH_X3(0, 1);
+                else LAUNCH_X3(1, 1);
+            } else {
+                if (prof == 0) LAUNCH_X3(0, 0);
+                else LAUNCH_X3(1, 0);
+            }
+#undef LAUNCH_X3
+            return hipGetLastError();
+        }
         if (a.tail_n > 0) {  // tail GEMM variant: one tile per workgroup, start / end stamps at most
             if (a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias)
                 return hipErrorInvalidValue;
@@ -934,7 +1045,7 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
             return hipGetLastError();
         }
     }
-    if (a.tail_n > 0) return hipErrorInvalidValue;
+    if (a.tail_n > 0 || a.x3) return hipErrorInvalidValue;
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
         if (a.bone) {  // bone-length features inside the transposed conv's launch: one tile per workgroup again
             if (a.items > maxwg || a.ksplit != 1 || a.Npad != 192 || a.ldc < 212) return hipErrorInvalidValue;
@@ -988,6 +1099,9 @@ static hipError_t setup_stream()
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 0, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 0, true>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 2>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 2>);
+        static_assert(x3_lds() <= stream_lds<64, 64, 1, 5>(), "the split-product ring fits the same LDS allowance");
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 0, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 0, false, true>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 1, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 1, false, true>);
     }
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());

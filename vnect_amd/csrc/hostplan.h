@@ -209,6 +209,31 @@ inline float from_bf16(uint16_t b)
     return f;
 }
 
+// fp32 -> three bf16 pieces, hi + mid + lo ~= x to 24 bits (each piece rounded to nearest even from what the previous ones left: the
+// pieces may differ in sign).  The split-product conv path (VNECT_FP32_SPLIT) stores its WEIGHTS this way; the kernel splits the
+// activations the same way in registers (by truncation, which is exact) and multiplies piece by piece on the bf16 matrix pipe.
+inline void split3(float x, uint16_t out[3])
+{
+    const uint16_t h = to_bf16(x);
+    const float r1 = x - from_bf16(h);            // exact: x and its bf16 neighbour share the exponent range
+    const uint16_t m = to_bf16(r1);
+    const float r2 = r1 - from_bf16(m);           // exact
+    out[0] = h, out[1] = m, out[2] = to_bf16(r2);
+}
+// packed fp32 weights [Npad][K] (K a multiple of 32) -> [Npad][K / 32][3 planes][32] bf16: per row and 32-element K chunk the hi, mid
+// and lo pieces of the chunk's weights, 64 bytes each (what one LDS-DMA landing of the split-product path fetches as three 64-byte rows)
+inline void pack_split3(const std::vector<float>& wp, int Npad, int K, std::vector<uint16_t>& out)
+{
+    out.assign((size_t)Npad * K * 3, 0);
+    for (int n = 0; n < Npad; n++)
+        for (int c = 0; c < K / 32; c++)
+            for (int e = 0; e < 32; e++) {
+                uint16_t pc[3];
+                split3(wp[(size_t)n * K + c * 32 + e], pc);
+                for (int pl = 0; pl < 3; pl++) out[(((size_t)n * (K / 32) + c) * 3 + pl) * 32 + e] = pc[pl];
+            }
+}
+
 inline void same_pad(int in, int k, int stride, int* out, int* before)
 {
     *out = (in + stride - 1) / stride;

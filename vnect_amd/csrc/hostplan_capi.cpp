@@ -156,6 +156,13 @@ void hp_fold_bn(const float* g, const float* b, const float* m, const float* v, 
     plan::fold_bn(g, b, m, v, C, Npad, bb, sc, sh);
     memcpy(bias, bb.data(), Npad * sizeof(float)), memcpy(scale, sc.data(), Npad * sizeof(float)), memcpy(shift, sh.data(), Npad * sizeof(float));
 }
+void hp_pack_split3(const float* wp, int Npad, int K, uint16_t* out)
+{
+    std::vector<float> v(wp, wp + (size_t)Npad * K);
+    std::vector<uint16_t> o;
+    plan::pack_split3(v, Npad, K, o);
+    memcpy(out, o.data(), o.size() * 2);
+}
 uint16_t hp_to_bf16(float f) { return plan::to_bf16(f); }
 float hp_from_bf16(uint16_t b) { return plan::from_bf16(b); }
 

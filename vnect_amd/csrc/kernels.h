@@ -60,6 +60,8 @@ struct ConvArgs {
     // (res2*_branch2b -> res2*_branch2c, vnect_model.py:38-41,50-53,56-59.)
     const float* tail_w;
     const float* tail_bias;
+    int x3;       // 1: split-product form (VNECT_FP32_SPLIT): `w` holds [Npad][K / 32][3 planes][32] bf16 (hostplan.h: pack_split3), the kernel
+                  // splits the fp32 activations three ways in registers and multiplies piece by piece on the bf16 matrix pipe
     int bone;     // 1: FUSE = 2 launch of the transposed conv: the bone-length columns 191 .. 211 (+ zero padding) are written here too
     int tail_n;   // 0: no tail; else the 1x1 conv's output channels (256: 2 row halves x 8 column blocks over the 8 waves)
 };

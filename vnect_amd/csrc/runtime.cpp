@@ -64,6 +64,7 @@ struct vnect_handle {
     std::string err;
     bool finalized = false;
     bool pre_only = false;  // vnect_config::preprocess_only: the input batch buffer and the resize tables, nothing else
+    bool x3 = false;    // VNECT_FP32_SPLIT: fp32 tensors; the 64x64-tile layers multiply on the bf16 pipe by three-way splits (conv.hip, X3)
     bool bf16 = false;  // VNECT_BF16: bf16 activations + weights, fp32 accumulate; final maps and post-processing stay fp32/f64
     hipStream_t st = nullptr;
     std::map<std::string, HostArray> weights;
@@ -244,6 +245,21 @@ int upload_weights(vnect_handle* h, float** dst, const std::vector<float>& v)
     return rc;
 }
 
+// Weights of a layer in the layout its launch reads: the split-product form (conv.hip, X3) for 64x64-tile layers of a VNECT_FP32_SPLIT
+// handle -- three bf16 planes per row and 32-element K chunk -- else upload_weights.  Sets a.x3.
+int upload_layer_weights(vnect_handle* h, Layer& L, const std::vector<float>& wp)
+{
+    ConvArgs& a = L.a;
+    a.x3 = h->x3 && !h->bf16 && L.BM == 64 && L.BN == 64 && L.KG == 1 && !a.pixmode && a.nphase <= 1 && a.K % 32 == 0 && !getenv("VNECT_NO_X3");
+    if (!a.x3) return upload_weights(h, &L.w, wp);
+    std::vector<uint16_t> pl;
+    plan::pack_split3(wp, a.Npad, a.K, pl);
+    uint16_t* p = nullptr;
+    int rc = upload(h, &p, pl);
+    L.w = (float*)p;
+    return rc;
+}
+
 // ---- tables: the arithmetic is in hostplan.h (HIP-free, sanitizer-tested on the CPU box); here they are built and uploaded ----
 int build_scale_tables(vnect_handle* h)
 {
@@ -386,7 +402,7 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
     std::vector<float> wp((size_t)a.Npad * a.K, 0.f), bp(a.Npad, 0.f);
     plan::pack_conv(W->d.data(), sp.k, cin, sp.cout, cp, conv1, h->bf16, a.K, 0, wp);
     for (int n = 0; n < sp.cout; n++) bp[n] = B->d[n];
-    if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
+    if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp)) return -1;
     h->layers.push_back(L);
     return L.out;
 }
@@ -437,7 +453,7 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     plan::pack_conv(Wb->d.data(), k, cin, cout_b, tin.Cs, false, h->bf16, a.K, cout_a, wp);
     for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
     for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
-    if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp)) return -1;
+    if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp)) return -1;
     h->layers.push_back(L);
     *second = L.out2;
     return L.out;
@@ -487,7 +503,7 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     plan::pack_tail(Wc->d.data(), mid, cout, w2);
     for (int n = 0; n < cout; n++) b2[n] = Bc->d[n];
     float *dw2 = nullptr, *db2 = nullptr;
-    if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
+    if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
     a.tail_w = dw2, a.tail_bias = db2, a.tail_n = cout;
     h->layers.push_back(L);
     return L.out;
@@ -1341,8 +1357,8 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
             return fail(nullptr, VNECT_E_ARG, "vnect_create: bad config (struct_size mismatch)");
         if (cfg->num_scales < 1 || cfg->num_scales > VNECT_MAX_SCALES)
             return fail(nullptr, VNECT_E_ARG, "vnect_create: num_scales out of range");
-        if (cfg->precision != VNECT_FP32 && cfg->precision != VNECT_BF16)
-            return fail(nullptr, VNECT_E_ARG, "vnect_create: precision must be VNECT_FP32 or VNECT_BF16");
+        if (cfg->precision != VNECT_FP32 && cfg->precision != VNECT_BF16 && cfg->precision != VNECT_FP32_SPLIT)
+            return fail(nullptr, VNECT_E_ARG, "vnect_create: precision must be VNECT_FP32, VNECT_BF16 or VNECT_FP32_SPLIT");
         if (cfg->lanes < 0 || cfg->lanes > RING - 1)
             return fail(nullptr, VNECT_E_ARG, "vnect_create: lanes must be 0 .. 3");
         if (cfg->exchange != VNECT_XCHG_RCCL && cfg->exchange != VNECT_XCHG_P2P)
@@ -1364,6 +1380,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         h->S = cfg->num_scales;
         h->Snet = sharded ? 1 : cfg->num_scales;
         h->bf16 = cfg->precision == VNECT_BF16;
+        h->x3 = cfg->precision == VNECT_FP32_SPLIT;
         h->sharded = sharded;
         h->keep_activations = cfg->keep_activations != 0;
         const bool pre = cfg->preprocess_only != 0;

@@ -37,7 +37,7 @@ class VNectEstimator:
             weights = synthetic_weights(seed)
         else:
             check_schema(weights)
-        self._cfg = dict(device=device, precision={"fp32": _native.FP32, "bf16": _native.BF16}[precision],
+        self._cfg = dict(device=device, precision={"fp32": _native.FP32, "bf16": _native.BF16, "fp32_split": _native.FP32_SPLIT}[precision],
                          paper_res2c=paper_res2c, use_graph=use_graph,
                          numpy_promotion={"legacy": 0, "nep50": 1}[numpy_promotion], lanes=lanes)
         self._submitted = 0
