@@ -944,7 +944,9 @@ def test_split_product_path_meets_the_fp32_gates(weights, oracle_net):
     hs.close(), hf.close()
     arena = _handle(BASELINE_SCALES, weights, precision=n.FP32_SPLIT)
     assert any(">" in L["name"] for L in arena.layers())           # the tail-fused launches are in this plan
-    assert np.array_equal(arena.forward(batch), out_s)
+    # (the arena plan's tail GEMMs multiply with the fp32 instruction, the private-buffer plan's stand-alone 1x1 layers by splits: equal
+    # to fp32 rounding, not bit for bit -- in this mode the last bits depend on the launch plan, like any change of summation order)
+    assert float(np.abs(arena.forward(batch) - out_s).max()) <= 2e-5 * float(np.abs(ref).max())
     e2e = _EndToEnd(BASELINE_SCALES, oracle_net)
     for k, (H, W) in enumerate([(368, 368), (538, 368), (240, 320), (368, 368)]):
         frame = helpers.synth_frame(8800 + k, H, W, smooth=True)

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
 {
     constexpr bool TAIL = FUSE == 1, BONE = FUSE == 2;
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
-    static_assert(!X3 || (BM == 64 && BN == 64 && KG == 1 && !BF && !SPAN && FUSE != 2 && PROF < 2), "split-product form: 64x64 tiles of fp32 layers");
+    static_assert(!X3 || (BM == 64 && (BN * KG == 64) && !BF && !SPAN && PROF < 2), "split-product form: 64x64 and 64x32x2 tiles of fp32 layers");
     static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1), "the fused forms are built for one 64x64 tile per workgroup");
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     constexpr int ARB = BM / 32, BRB = BN / 32, WMN = ARB * BRB;  // 32-row blocks of A and B; accumulators per K group
     constexpr int BROWF = X3 ? 48 : 32;                          // floats per B row and chunk (X3: three 64-byte planes, plane-major in the stage)
     constexpr int ROWS = BM + BN, SUB = BM * 32 + BN * BROWF;    // one K group's image: BM A rows x 128 B, then the B rows
-    constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : (X3 ? ARB + 3 : KG * ROWS / 32);  // floats per ring stage; LDS-DMA instructions per producer wave per step
+    constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : (X3 ? KG * ARB + 3 : KG * ROWS / 32);  // floats per ring stage; LDS-DMA instructions per producer wave per step
     constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x 4 KiB, then WMN*(KG-1) flags
     constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
     static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
@@ -457,12 +457,17 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 }
             }
             if constexpr (X3) {
-                // plane pl of this wave's 16 weight rows: LDS slot (row 16 wave + (lane >> 2), 16-byte unit lane & 3) takes source unit
-                // (lane & 3) ^ ((row >> 2) & 3) -- the XOR that spreads a fragment read's 16 rows x 64 B over all banks
-                const int brow = wave * 16 + (lane >> 2), bun = (lane & 3) ^ ((brow >> 2) & 3);
+                // A step's weights are KG x 3 planes x BN rows x 64 B = 12 blocks of 16 rows: wave w lands blocks 3 w .. 3 w + 2.  Block ->
+                // (K group, plane, 16-row group); LDS slot (row, 16-byte unit lane & 3) takes source unit (lane & 3) ^ ((row >> 2) & 3) --
+                // the XOR that spreads a fragment read's 16 rows x 64 B over all banks
+                constexpr int PER_KG = 3 * BN / 16, RG = BN / 16;
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) b_vo3[pl] = (unsigned)((it.n0 + brow) * (p.K / 32) * 192 + pl * 64 + bun * 16);
-                soB = (unsigned)__builtin_amdgcn_readfirstlane(it.c0 * 192);
+                for (int j = 0; j < 3; j++) {
+                    const int blk = 3 * wave + j, kgi = blk / PER_KG, rr = blk % PER_KG, pl = rr / RG, rg = rr % RG;
+                    const int brow = rg * 16 + (lane >> 2), bun = (lane & 3) ^ ((brow >> 2) & 3);
+                    b_vo3[j] = (unsigned)((it.n0 + brow) * (p.K / 32) * 192 + kgi * 192 + pl * 64 + bun * 16);
+                }
+                soB = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.phase * p.w_phase_stride * 6 + (long long)it.c0 * (192 * KG)));
             } else {
 #pragma unroll
                 for (int i = 0; i < BRB; i++) b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
@@ -481,12 +486,18 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             for (int k = 0; k < KG; k++) {  // K group k: the k-th 128-byte run of the step, landed in its own image
 #pragma unroll
                 for (int i = 0; i < (SPAN ? 1 : ARB); i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
-                if constexpr (X3) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++) bload_lds(srdB, sb + BM * 32 + pl * (BN * 16), b_vo3[pl], uB);
-                } else {
+                if constexpr (!X3) {
 #pragma unroll
                     for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], uB + k * 128);
+                }
+            }
+            if constexpr (X3) {
+                constexpr int PER_KG = 3 * BN / 16, RG = BN / 16;
+                float* s0 = smem + __builtin_amdgcn_readfirstlane(stage) * STAGE;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int blk = 3 * wave + j, kgi = blk / PER_KG, rr = blk % PER_KG, pl = rr / RG, rg = rr % RG;  // wave-uniform
+                    bload_lds(srdB, s0 + kgi * SUB + BM * 32 + pl * (BN * 16) + rg * 256, b_vo3[j], uB);
                 }
             }
             rem = __builtin_amdgcn_readfirstlane(rem - 1);
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 jn = __builtin_amdgcn_readfirstlane(jn + 1);
                 if (jn < my_n) begin_item(jn);
             } else {
-                soA += 128 * KG, soB += X3 ? 192 : 128 * KG;
+                soA += 128 * KG, soB += X3 ? 192 * KG : 128 * KG;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
             }
         };
@@ -670,65 +681,88 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
 
     // ---- X3: the split-product K loop (see the kernel's head comment).  A chunk = two K steps of 16; the operands of a K step are
     // the lane's 8 fp32 activations (two 16-byte units of the A row) and 8 bf16 of each weight plane (one unit of the plane's row).
-    // Always one K step ahead: while step 0 multiplies, step 1's operands are read from the same stage; while step 1 multiplies, step
-    // 0 of the NEXT chunk (visible since this chunk's barrier) is read.
-    struct Kx {
-        f32x4 a0, a1, b[3];
+    // Software pipeline over K steps i = 2 chunk + s, three stages deep, register sets by parity of i:
+    //     iteration i:  read raw A(i + 2) and B(i + 1) from LDS | split A(i + 1) into its three bf16 pieces (VALU) | 6 MFMAs of step i
+    // so the split's ~44 VALU instructions sit BETWEEN the dependent MFMAs of the step before (a wave issues in order: left in front of
+    // them they cost as much as the matrix work itself) and every LDS read has a whole K step to land.  Steps i + 1, i + 2 lie in
+    // chunk g or g + 1, both visible since chunk g's barrier.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct Asp {
+        u32x4 h, m, l;  // 8 bf16 each: hi, mid, lo pieces
     };
-    Kx R0 = {}, R1 = {};
+    f32x4 rawA[2][2] = {};
+    f32x4 Bq[2][3] = {};
+    Asp Aq[2] = {};
     int foA3[2][2] = {{0, 0}, {0, 0}}, foB3[2] = {0, 0};
     if constexpr (X3) {
         const int sw = (lane >> 1) & 7, swb = (lane >> 2) & 3;  // (row >> 1) & 7 of the A row, (row >> 2) & 3 of the B row: rows are 32 wm / wn + (lane & 31)
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
-            for (int j2 = 0; j2 < 2; j2++) foA3[s2][j2] = (wm * 32 + (lane & 31)) * 32 + (((4 * s2 + 2 * (lane >> 5) + j2) ^ sw) * 4);
-            foB3[s2] = BM * 32 + (wn * 32 + (lane & 31)) * 16 + (((2 * s2 + (lane >> 5)) ^ swb) * 4);
+            for (int j2 = 0; j2 < 2; j2++) foA3[s2][j2] = kg * SUB + (wm * 32 + (lane & 31)) * 32 + (((4 * s2 + 2 * (lane >> 5) + j2) ^ sw) * 4);
+            foB3[s2] = kg * SUB + BM * 32 + (wn * 32 + (lane & 31)) * 16 + (((2 * s2 + (lane >> 5)) ^ swb) * 4);
         }
     }
-    auto ldx = [&](Kx& R, int stg, int s2) __attribute__((always_inline)) {
+    auto ldA = [&](int par, int stg, int s2) __attribute__((always_inline)) {
         const float* sb = smem + stg * STAGE;
-        R.a0 = *(const f32x4*)(sb + foA3[s2][0]), R.a1 = *(const f32x4*)(sb + foA3[s2][1]);
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) R.b[pl] = *(const f32x4*)(sb + foB3[s2] + pl * (BN * 16));
+        rawA[par][0] = *(const f32x4*)(sb + foA3[s2][0]), rawA[par][1] = *(const f32x4*)(sb + foA3[s2][1]);
     };
-    auto mmx = [&](const Kx& R) __attribute__((always_inline)) {
-        // x = hi + mid + lo by truncation (exact): hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of x - hi - mid
-        unsigned xb[8], hb[8], mb[8], lb[8];
+    auto ldB = [&](int par, int stg, int s2) __attribute__((always_inline)) {
+        const float* sb = smem + stg * STAGE + foB3[s2];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const float x = e < 4 ? R.a0[e & 3] : R.a1[e & 3];
-            xb[e] = __builtin_bit_cast(unsigned, x);
-            const float r1 = x - __builtin_bit_cast(float, xb[e] & 0xffff0000u);
-            hb[e] = xb[e];
+        for (int pl = 0; pl < 3; pl++) Bq[par][pl] = *(const f32x4*)(sb + pl * (BN * 16));
+    };
+    // pieces of elements 2 q, 2 q + 1 of the raw A set `par`: x = hi + mid + lo by truncation (exact): hi = top 16 bits of x, mid = top 16
+    // bits of x - hi, lo = top 16 bits of x - hi - mid; two bf16 per dword (the high halves of elements 2 q + 1 and 2 q).  11 VALU ops.
+    auto split2 = [&](int par, int q) __attribute__((always_inline)) {
+        unsigned hb[2], mb[2], lb[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float x = rawA[par][q >> 1][2 * (q & 1) + e];
+            hb[e] = __builtin_bit_cast(unsigned, x);
+            const float r1 = x - __builtin_bit_cast(float, hb[e] & 0xffff0000u);
             mb[e] = __builtin_bit_cast(unsigned, r1);
             lb[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb[e] & 0xffff0000u));
         }
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 H, Mi, L;
+        Aq[par].h[q] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+        Aq[par].m[q] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+        Aq[par].l[q] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+    };
+    auto splitA = [&](int par) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // two bf16 per dword: the high halves of elements 2 q + 1 and 2 q
-            H[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);
-            Mi[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
-            L[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
-        }
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, H), am = __builtin_bit_cast(bf16x8, Mi), al = __builtin_bit_cast(bf16x8, L);
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, R.b[0]), wmid = __builtin_bit_cast(bf16x8, R.b[1]), wl = __builtin_bit_cast(bf16x8, R.b[2]);
-        // smallest terms first
+        for (int q = 0; q < 4; q++) split2(par, q);
+    };
+    auto kstep = [&](int par, int stgA, int sA, int stgB, int sB) __attribute__((always_inline)) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, Aq[par].h), am = __builtin_bit_cast(bf16x8, Aq[par].m), al = __builtin_bit_cast(bf16x8, Aq[par].l);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, Bq[par][0]), wmid = __builtin_bit_cast(bf16x8, Bq[par][1]), wl = __builtin_bit_cast(bf16x8, Bq[par][2]);
+        ldA(par, stgA, sA);        // raw A of step i + 2
+        ldB(par ^ 1, stgB, sB);    // weights of step i + 1
+        __builtin_amdgcn_sched_barrier(0);
+        // the six (dependent) MFMAs of step i, smallest terms first, with the split of step i + 1's activations between them: a wave
+        // issues in order, so VALU work placed in front of (or behind) the chain would cost as much time as the matrix work itself.
+        // Hard scheduling fences: the hints (sched_group_barrier) were honoured in one of the two unrolled K steps only.
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wmid, acc, 0, 0, 0);
+        split2(par ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+        split2(par ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+        split2(par ^ 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+        split2(par ^ 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wmid, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
     };
     auto step3 = [&]() __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
         __builtin_amdgcn_s_barrier();  // chunk g+1 visible; every consumer is past chunk g-1
-        ldx(R1, stage, 1);
-        mmx(R0);
-        ldx(R0, nstage, 0);
-        mmx(R1);
+        kstep(0, nstage, 0, stage, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(1, nstage, 1, nstage, 0);
+        __builtin_amdgcn_sched_barrier(0);
         stage = nstage;
     };
 
@@ -754,8 +788,11 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     __builtin_amdgcn_s_barrier();  // chunk 0 visible
     if (pstamp) prof[11] = __builtin_amdgcn_s_memrealtime();
     if constexpr (SPAN) set_span(decode(0).m0);
-    if constexpr (X3) ldx(R0, 0, 0);
-    else rall(0, F0);
+    if constexpr (X3) {  // pipeline prologue: step 0's weights and pieces, step 1's raw A (chunk 0 is visible)
+        ldA(0, 0, 0), ldB(0, 0, 0), ldA(1, 0, 1);
+        splitA(0);
+    } else
+        rall(0, F0);
     for (int j = 0; j < my_n; j++) {
         const Item it = decode(j);
         if constexpr (SPAN) {
@@ -991,8 +1028,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 
 template <int BM, int BN, int KG, int NS>
 constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
-constexpr int X3_NS = 4;  // split-product form: 4 stages of 64 x 128 B + 64 x 192 B = 20 KiB (the same 80 KB as 5 x 16 KiB)
-constexpr size_t x3_lds() { return (size_t)X3_NS * (64 * 32 + 64 * 48) * 4; }
+// split-product form: a stage holds BM x 128 B of activations and BN x 192 B of weight planes per K group
+template <int BM, int BN, int KG, int NS>
+constexpr size_t x3_stream_lds() { return (size_t)NS * (BM * 32 + BN * 48) * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
+constexpr int X3_NS = 4;  // 64x64: 4 stages of 20 KiB (the same 80 KB as 5 x 16 KiB: two workgroups per CU)
+constexpr size_t x3_lds() { return x3_stream_lds<64, 64, 1, X3_NS>(); }
 
 template <int BM, int BN, int KG, int NS>
 static hipError_t launch_stream(ConvArgs a, hipStream_t st)
@@ -1016,7 +1056,13 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
 #define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a)
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
         if (a.x3) {  // split-product form (plain or with the tail GEMM behind it); start / end stamps at most
-            if (a.bf16 || a.pixmode || a.nphase != 1 || a.bone || a.K % 32) return hipErrorInvalidValue;
+            if (a.bf16 || a.pixmode || a.K % 32) return hipErrorInvalidValue;
+            if (a.bone) {  // + the bone-length features behind the transposed conv's K loop
+                if (a.items > maxwg || a.ksplit != 1 || a.Npad != 192 || a.ldc < 212 || a.tail_n > 0) return hipErrorInvalidValue;
+                if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 2, false, true>), grid, dim3(512), x3_lds(), st, a);
+                else hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 2, false, true>), grid, dim3(512), x3_lds(), st, a);
+                return hipGetLastError();
+            }
             if (a.tail_n > 0 && (a.items > maxwg || a.ksplit != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias))
                 return hipErrorInvalidValue;
 #define LAUNCH_X3(PR, FU) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, PR, FU, false, true>), grid, dim3(512), x3_lds(), st, a)
@@ -1042,6 +1088,15 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
                 else LAUNCH_TAIL(false, 1);
             }
 #undef LAUNCH_TAIL
+            return hipGetLastError();
+        }
+    }
+    if constexpr (BM == 64 && BN == 32 && KG == 2) {
+        if (a.x3) {  // split-product form of the in-workgroup K-group shape (one workgroup per CU; 5 stages of 28 KiB)
+            if (a.bf16 || a.pixmode || a.K % 32 || a.tail_n > 0 || a.bone) return hipErrorInvalidValue;
+            const size_t l3 = x3_stream_lds<64, 32, 2, NS>();
+            if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>), grid, dim3(512), l3, st, a);
+            else hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>), grid, dim3(512), l3, st, a);
             return hipGetLastError();
         }
     }
@@ -1102,6 +1157,16 @@ static hipError_t setup_stream()
         static_assert(x3_lds() <= stream_lds<64, 64, 1, 5>(), "the split-product ring fits the same LDS allowance");
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 0, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 0, false, true>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 1, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 1, false, true>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 2, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 2, false, true>);
+    }
+    if constexpr (BM == 64 && BN == 32 && KG == 2) {
+        for (const void* f : {(const void*)conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_stream_lds<64, 32, 2, NS>());
+            if (e != hipSuccess) return e;
+            e = hipFuncGetAttributes(&fa, f);
+            if (e != hipSuccess) return e;
+            if (fa.numRegs > 256 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
+        }
     }
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());

@@ -250,10 +250,10 @@ int upload_weights(vnect_handle* h, float** dst, const std::vector<float>& v)
 int upload_layer_weights(vnect_handle* h, Layer& L, const std::vector<float>& wp)
 {
     ConvArgs& a = L.a;
-    a.x3 = h->x3 && !h->bf16 && L.BM == 64 && L.BN == 64 && L.KG == 1 && !a.pixmode && a.nphase <= 1 && a.K % 32 == 0 && !getenv("VNECT_NO_X3");
+    a.x3 = h->x3 && !h->bf16 && L.BM == 64 && L.BN * L.KG == 64 && !a.pixmode && a.K % 32 == 0 && !getenv("VNECT_NO_X3");
     if (!a.x3) return upload_weights(h, &L.w, wp);
     std::vector<uint16_t> pl;
-    plan::pack_split3(wp, a.Npad, a.K, pl);
+    plan::pack_split3(wp, a.Npad * std::max(a.nphase, 1), a.K, pl);  // (the transposed conv: 4 phases x Npad rows)
     uint16_t* p = nullptr;
     int rc = upload(h, &p, pl);
     L.w = (float*)p;
@@ -709,7 +709,7 @@ int finalize_impl(vnect_handle* h)
         plan::pack_deconv(W1->d.data(), W2->d.data(), a.Npad, a.K, wp, L.dy, L.dx);
         // FusedBatchNorm inference (contrib batch_norm default epsilon 0.001): (x - mean) * (gamma * rsqrt(var + eps)) + beta
         plan::fold_bn(ga->d.data(), be->d.data(), mu->d.data(), va->d.data(), 128, a.Npad, bp, sc, sh);
-        if (upload_weights(h, &L.w, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
+        if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp) || upload(h, &L.scale, sc) || upload(h, &L.shift, sh))
             return VNECT_E_HIP;
         // bone-length features (vnect_model.py:198-209): inside this launch (conv.hip, FUSE = 2) where every workgroup has one tile,
         // i.e. up to 5 scales; as a launch of their own otherwise, and when per-layer read-back is requested
