@@ -219,23 +219,23 @@ def test_bf16_rounding_is_nearest_even(hp):
 
 
 def test_split3_planes_reconstruct_the_weights(hp):
-    """pack_split3 (the split-product path's weight layout: per row and 32-element K chunk three 64-byte planes hi / mid / lo of bf16):
+    """pack_split3 (the split-product path's weight layout: per 32-element K chunk three planes hi / mid / lo of [rows][32] bf16):
     hi + mid + lo reproduces every fp32 weight to within one unit of its 24th bit, hi is the weight's bf16 rounding, and the planes
     sit where the kernel's LDS-DMA addressing expects them."""
     rng = np.random.RandomState(9)
     Npad, K = 64, 96
     wp = (rng.randn(Npad, K) * np.exp(rng.uniform(-6, 3, (Npad, K)))).astype(np.float32)
     wp[0, :4] = [0.0, -0.0, 1.0, -3.0e-12]
-    out = np.zeros((Npad, K // 32, 3, 32), np.uint16)
+    out = np.zeros((K // 32, 3, Npad, 32), np.uint16)                                  # chunk-major: [chunk][plane][row][32]
     hp.hp_pack_split3.argtypes = [f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16)]
     hp.hp_pack_split3(_p(wp, f32p), Npad, K, _p(out, C.POINTER(C.c_uint16)))
     planes = (out.astype(np.uint32) << 16).view(np.float32).astype(np.float64)          # bf16 -> value
-    total = planes.sum(axis=2).reshape(Npad, K)
+    total = planes.sum(axis=1).transpose(1, 0, 2).reshape(Npad, K)
     w64 = wp.astype(np.float64)
     assert np.all(np.abs(total - w64) <= np.abs(w64) * 2.0 ** -23 + 1e-300)
     u = wp.view(np.uint32).astype(np.uint64)
     hi_want = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16).reshape(Npad, K // 32, 32)
-    assert np.array_equal(out[:, :, 0, :], hi_want)
+    assert np.array_equal(out[:, 0, :, :].transpose(1, 0, 2), hi_want)
 
 
 # ------------------------------------------------------------------------------------------ arena, tiles, stem

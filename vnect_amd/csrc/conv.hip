@@ -11,6 +11,10 @@
 // weights, [N][K]) chunks go global -> LDS by buffer-addressed LDS-DMA into a ring of stages (details at the kernel).
 #include "kernels.h"
 
+#ifndef X3_DBG
+#define X3_DBG 0  // tuning builds only (make VARIANT=_b EXTRA=-DX3_DBG=n): timing probes of the split-product loop, wrong results
+#endif
+
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -465,9 +469,10 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 for (int j = 0; j < 3; j++) {
                     const int blk = 3 * wave + j, kgi = blk / PER_KG, rr = blk % PER_KG, pl = rr / RG, rg = rr % RG;
                     const int brow = rg * 16 + (lane >> 2), bun = (lane & 3) ^ ((brow >> 2) & 3);
-                    b_vo3[j] = (unsigned)((it.n0 + brow) * (p.K / 32) * 192 + kgi * 192 + pl * 64 + bun * 16);
+                    // global layout [chunk][plane][Npad rows][64 B]: the block's 16 rows are one contiguous KiB
+                    b_vo3[j] = (unsigned)(((kgi * 3 + pl) * a.Npad + it.n0 + brow) * 64 + bun * 16);
                 }
-                soB = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.phase * p.w_phase_stride * 6 + (long long)it.c0 * (192 * KG)));
+                soB = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.phase * p.w_phase_stride * 6 + (long long)it.c0 * KG * (192 * a.Npad)));
             } else {
 #pragma unroll
                 for (int i = 0; i < BRB; i++) b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
@@ -497,6 +502,10 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int blk = 3 * wave + j, kgi = blk / PER_KG, rr = blk % PER_KG, pl = rr / RG, rg = rr % RG;  // wave-uniform
+#if X3_DBG == 3  // timing probe (wrong results): the hi plane's bytes only (OOB lanes fetch nothing and land zeros)
+                    bload_lds(srdB, s0 + kgi * SUB + BM * 32 + pl * (BN * 16) + rg * 256, pl == 0 ? b_vo3[j] : 0x80000000u, uB);
+                    continue;
+#endif
                     bload_lds(srdB, s0 + kgi * SUB + BM * 32 + pl * (BN * 16) + rg * 256, b_vo3[j], uB);
                 }
             }
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 jn = __builtin_amdgcn_readfirstlane(jn + 1);
                 if (jn < my_n) begin_item(jn);
             } else {
-                soA += 128 * KG, soB += X3 ? 192 * KG : 128 * KG;
+                soA += 128 * KG, soB += X3 ? 192 * KG * a.Npad : 128 * KG;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
             }
         };
@@ -720,9 +729,13 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         for (int e = 0; e < 2; e++) {
             const float x = rawA[par][q >> 1][2 * (q & 1) + e];
             hb[e] = __builtin_bit_cast(unsigned, x);
+#if X3_DBG == 1  // timing probe (wrong results): no split arithmetic
+            mb[e] = hb[e], lb[e] = hb[e];
+#else
             const float r1 = x - __builtin_bit_cast(float, hb[e] & 0xffff0000u);
             mb[e] = __builtin_bit_cast(unsigned, r1);
             lb[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb[e] & 0xffff0000u));
+#endif
         }
         Aq[par].h[q] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
         Aq[par].m[q] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
@@ -741,6 +754,17 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         // the six (dependent) MFMAs of step i, smallest terms first, with the split of step i + 1's activations between them: a wave
         // issues in order, so VALU work placed in front of (or behind) the chain would cost as much time as the matrix work itself.
         // Hard scheduling fences: the hints (sched_group_barrier) were honoured in one of the two unrolled K steps only.
+#if X3_DBG == 2  // timing probe (wrong results): half the matrix work
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wmid, acc, 0, 0, 0);
+        split2(par ^ 1, 0);
+        split2(par ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wl, acc, 0, 0, 0);
+        split2(par ^ 1, 2);
+        split2(par ^ 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+#else
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wmid, acc, 0, 0, 0);
         split2(par ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -755,6 +779,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wmid, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+#endif
     };
     auto step3 = [&]() __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
@@ -1055,24 +1080,25 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     const int prof = a.prof ? (detail ? 2 : 1) : 0;
 #define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a)
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
-        if (a.x3) {  // split-product form (plain or with the tail GEMM behind it); start / end stamps at most
+        if (a.x3) {  // split-product form (plain, with the tail GEMM or with the bone features behind it); start / end stamps at most
             if (a.bf16 || a.pixmode || a.K % 32) return hipErrorInvalidValue;
-            if (a.bone) {  // + the bone-length features behind the transposed conv's K loop
-                if (a.items > maxwg || a.ksplit != 1 || a.Npad != 192 || a.ldc < 212 || a.tail_n > 0) return hipErrorInvalidValue;
-                if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 2, false, true>), grid, dim3(512), x3_lds(), st, a);
-                else hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 2, false, true>), grid, dim3(512), x3_lds(), st, a);
-                return hipGetLastError();
-            }
+            if (a.bone && (a.items > maxwg || a.ksplit != 1 || a.Npad != 192 || a.ldc < 212 || a.tail_n > 0)) return hipErrorInvalidValue;
             if (a.tail_n > 0 && (a.items > maxwg || a.ksplit != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias))
                 return hipErrorInvalidValue;
-#define LAUNCH_X3(PR, FU) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, X3_NS, false, PR, FU, false, true>), grid, dim3(512), x3_lds(), st, a)
-            if (a.tail_n > 0) {
-                if (prof == 0) LAUNCH_X3(0, 1);
-                else LAUNCH_X3(1, 1);
-            } else {
-                if (prof == 0) LAUNCH_X3(0, 0);
-                else LAUNCH_X3(1, 0);
-            }
+            // (Measured, A/B in one call each: a 7-stage ring for launches with one workgroup per CU 1 162 vs 1 174 frames/s without; the
+            // hi plane's bytes only -- 12 KiB per chunk instead of 20 -- +1.6 %; no split arithmetic +13 %; 3 MFMAs instead of 6 +9 %:
+            // the loop is bound by the VALU + MFMA issue of the consumer waves, not by bytes into the LDS.  DESIGN 4.1d.)
+            const int fu = a.bone ? 2 : (a.tail_n > 0 ? 1 : 0);
+#define LAUNCH_X3(NSX, PR, FU) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NSX, false, PR, FU, false, true>), grid, dim3(512), (x3_stream_lds<64, 64, 1, NSX>()), st, a)
+#define LAUNCH_X3_FU(NSX, PR)                 \
+    do {                                      \
+        if (fu == 0) LAUNCH_X3(NSX, PR, 0);   \
+        else if (fu == 1) LAUNCH_X3(NSX, PR, 1); \
+        else LAUNCH_X3(NSX, PR, 2);           \
+    } while (0)
+            if (prof == 0) LAUNCH_X3_FU(X3_NS, 0);
+            else LAUNCH_X3_FU(X3_NS, 1);
+#undef LAUNCH_X3_FU
 #undef LAUNCH_X3
             return hipGetLastError();
         }
@@ -1155,9 +1181,19 @@ static hipError_t setup_stream()
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 2>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 2>);
         static_assert(x3_lds() <= stream_lds<64, 64, 1, 5>(), "the split-product ring fits the same LDS allowance");
-        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 0, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 0, false, true>);
-        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 1, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 1, false, true>);
-        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 2, false, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 2, false, true>);
+    }
+    if constexpr (BM == 64 && BN == 64 && KG == 1) {  // the split-product instantiations have LDS sizes of their own
+        static_assert(x3_lds() <= stream_lds<64, 64, 1, 5>(), "the split-product ring fits the two-workgroups-per-CU LDS allowance");
+        const void* x3s[] = {(const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 0, false, true>,
+                             (const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 1, false, true>, (const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 1, false, true>,
+                             (const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 0, 2, false, true>, (const void*)conv_stream_kernel<64, 64, 1, X3_NS, false, 1, 2, false, true>};
+        for (int i = 0; i < 6; i++) {
+            hipError_t e = hipFuncSetAttribute(x3s[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_stream_lds<64, 64, 1, X3_NS>());
+            if (e != hipSuccess) return e;
+            e = hipFuncGetAttributes(&fa, x3s[i]);
+            if (e != hipSuccess) return e;
+            if (fa.numRegs > 128 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
+        }
     }
     if constexpr (BM == 64 && BN == 32 && KG == 2) {
         for (const void* f : {(const void*)conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>}) {

@@ -220,18 +220,21 @@ inline void split3(float x, uint16_t out[3])
     const float r2 = r1 - from_bf16(m);           // exact
     out[0] = h, out[1] = m, out[2] = to_bf16(r2);
 }
-// packed fp32 weights [Npad][K] (K a multiple of 32) -> [Npad][K / 32][3 planes][32] bf16: per row and 32-element K chunk the hi, mid
-// and lo pieces of the chunk's weights, 64 bytes each (what one LDS-DMA landing of the split-product path fetches as three 64-byte rows)
-inline void pack_split3(const std::vector<float>& wp, int Npad, int K, std::vector<uint16_t>& out)
+// packed fp32 weights [phases][Npad][K] (K a multiple of 32) -> [phases][K / 32 chunks][3 planes][Npad][32] bf16: chunk-major, so that the
+// 64 bytes a plane holds per row and chunk lie NEXT to the neighbouring rows' (a landing of 16 rows x 64 B is one contiguous KiB: whole
+// cache lines, like the fp32 layout's 8 rows x 128 B; with the planes stored row by row every request was half a line)
+inline void pack_split3(const std::vector<float>& wp, int phases, int Npad, int K, std::vector<uint16_t>& out)
 {
-    out.assign((size_t)Npad * K * 3, 0);
-    for (int n = 0; n < Npad; n++)
-        for (int c = 0; c < K / 32; c++)
-            for (int e = 0; e < 32; e++) {
-                uint16_t pc[3];
-                split3(wp[(size_t)n * K + c * 32 + e], pc);
-                for (int pl = 0; pl < 3; pl++) out[(((size_t)n * (K / 32) + c) * 3 + pl) * 32 + e] = pc[pl];
-            }
+    out.assign((size_t)phases * Npad * K * 3, 0);
+    const int C = K / 32;
+    for (int z = 0; z < phases; z++)
+        for (int n = 0; n < Npad; n++)
+            for (int c = 0; c < C; c++)
+                for (int e = 0; e < 32; e++) {
+                    uint16_t pc[3];
+                    split3(wp[((size_t)z * Npad + n) * K + c * 32 + e], pc);
+                    for (int pl = 0; pl < 3; pl++) out[((((size_t)z * C + c) * 3 + pl) * Npad + n) * 32 + e] = pc[pl];
+                }
 }
 
 inline void same_pad(int in, int k, int stride, int* out, int* before)

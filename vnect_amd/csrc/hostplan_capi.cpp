@@ -160,7 +160,7 @@ void hp_pack_split3(const float* wp, int Npad, int K, uint16_t* out)
 {
     std::vector<float> v(wp, wp + (size_t)Npad * K);
     std::vector<uint16_t> o;
-    plan::pack_split3(v, Npad, K, o);
+    plan::pack_split3(v, 1, Npad, K, o);
     memcpy(out, o.data(), o.size() * 2);
 }
 uint16_t hp_to_bf16(float f) { return plan::to_bf16(f); }

@@ -253,7 +253,7 @@ int upload_layer_weights(vnect_handle* h, Layer& L, const std::vector<float>& wp
     a.x3 = h->x3 && !h->bf16 && L.BM == 64 && L.BN * L.KG == 64 && !a.pixmode && a.K % 32 == 0 && !getenv("VNECT_NO_X3");
     if (!a.x3) return upload_weights(h, &L.w, wp);
     std::vector<uint16_t> pl;
-    plan::pack_split3(wp, a.Npad * std::max(a.nphase, 1), a.K, pl);  // (the transposed conv: 4 phases x Npad rows)
+    plan::pack_split3(wp, std::max(a.nphase, 1), a.Npad, a.K, pl);  // (the transposed conv: 4 phases)
     uint16_t* p = nullptr;
     int rc = upload(h, &p, pl);
     L.w = (float*)p;
