@@ -297,9 +297,14 @@ def main():
 
     graph_mode = False if args.no_graph else (True if args.graph else "auto")
     job = None
+    rehearsal_note = None
     if args.pyramid:
         if args.gpus != len(SCALES):
             sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
+        if args.pyramid_both and dev_override is not None:
+            # one-GPU rehearsal: RCCL refuses several ranks on one device ("invalid usage"), so only the peer-write leg can run here
+            args.pyramid_both, args.exchange = False, "p2p"
+            rehearsal_note = "rehearsal on ONE device: the RCCL leg of --pyramid-both cannot run (RCCL refuses several ranks per device); p2p only"
         if args.pyramid_both:
             args.exchange = "rccl"   # first leg; the p2p leg follows the headline's timed region and profile
 
@@ -469,6 +474,7 @@ def main():
             "exchange": (("rccl: ncclAllGather of 710 976 B per rank" if args.exchange == "rccl" else "p2p: peer writes over xGMI")
                          if args.pyramid else None),
             "pyramid_p2p": pyramid_p2p,
+            "note": rehearsal_note if args.pyramid else None,
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
