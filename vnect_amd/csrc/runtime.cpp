@@ -1340,6 +1340,36 @@ int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int 
     return VNECT_OK;
 }
 
+// Warm start: a tracking loop wants its FIRST frames at steady-state speed, but the first ~25 frames behind vnect_finalize run 1.5-3 %
+// slower (shader clocks ramp up from idle, instruction and translation caches are cold -- measured).  So finalize runs
+// the launch plan a few times on a grey 368 x 368 frame in slot 0 (every lane once more, three in flight), then restores the state a fresh
+// handle has: empty slot, new filters, no timestamps.  VNECT_PRIME_FRAMES overrides the count (0 = off).  ~25 ms at start-up.
+int prime(vnect_handle* h)
+{
+    static const int n_env = getenv("VNECT_PRIME_FRAMES") ? atoi(getenv("VNECT_PRIME_FRAMES")) : 24;
+    if (n_env <= 0 || h->sharded || h->slots.empty() || (size_t)BOX * BOX * 3 > (size_t)h->cfg.max_frame_bytes) return VNECT_OK;
+    HIPCK(h, hipMemsetAsync(h->frames, 128, (size_t)BOX * BOX * 3, h->st));
+    HIPCK(h, hipStreamSynchronize(h->st));
+    h->slots[0].H = BOX, h->slots[0].W = BOX, h->slots[0].stride = (long long)BOX * 3;
+    int rc = VNECT_OK, ring = 0;
+    double t = 1.0;
+    for (int i = 0; i < n_env && !rc; i++, t += 1.0) {
+        rc = enqueue_frame(h, 0, t, t, &ring);
+        if (!rc) rc = collect_impl(h, nullptr, nullptr);
+    }
+    for (int rep = 0; rep < 2 && !rc && !h->twins.empty(); rep++) {  // the other lanes: as many frames in flight as there are lanes
+        const int depth = (int)h->twins.size() + 1;
+        for (int i = 0; i < depth && !rc; i++, t += 1.0) rc = enqueue_frame(h, 0, t, t, &ring);
+        for (int i = 0; i < depth && !rc; i++) rc = collect_impl(h, nullptr, nullptr);
+    }
+    h->slots[0] = vnect_handle::SlotInfo();
+    if (!rc) rc = reset_filters_impl(h);
+    for (int s = 0; s < VNECT_MAX_STREAMS; s++) h->stream_seq[s] = -1, h->stream_lane[s] = nullptr;
+    h->fp_dev_valid = false;  // (the next frame uploads its own geometry)
+    for (vnect_handle* tw : h->twins) tw->fp_dev_valid = false;
+    return rc;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1537,7 +1567,7 @@ int vnect_finalize(vnect_handle* h)
         HIPCK(h, hipStreamSynchronize(h->st));
         h->finalized = true;
         h->weights.clear();
-        return VNECT_OK;
+        return prime(h);
     });
 }
 
