@@ -320,3 +320,35 @@ def test_streams_on_one_handle_equal_handles_of_their_own(weights):
         shared.submit_stream(0, 0, times[0][-1], times[0][-1] + 0.001)
     assert e.value.code == _native.E_TIMESTAMP
     shared.close()
+
+
+def test_warm_start_leaves_a_fresh_handle(weights):
+    """vnect_finalize primes the launch plan on a grey frame (warm start).  Afterwards the handle must be indistinguishable from an
+    unprimed one (VNECT_PRIME_FRAMES=0): frames uploaded BEFORE finalize are intact, the first real frame is the filters' identity
+    frame, and a sequence gives the same joints bit for bit."""
+    import os
+    from vnect_amd import _native
+    from tests import helpers
+    frames = [helpers.synth_frame(9100 + k, 300, 368, smooth=True) for k in range(3)]
+
+    def run(prime):
+        old = os.environ.pop("VNECT_PRIME_FRAMES", None)
+        if not prime:
+            os.environ["VNECT_PRIME_FRAMES"] = "0"
+        try:
+            h = _native.Handle([1.0, 0.8], num_frame_slots=2, lanes=2)
+            h.upload_frame(0, frames[0])            # before finalize: must survive the priming
+            h.set_weights(weights)
+            h.finalize()
+        finally:
+            os.environ.pop("VNECT_PRIME_FRAMES", None)
+            if old is not None:
+                os.environ["VNECT_PRIME_FRAMES"] = old
+        out = [h.infer_resident(0, T0, T0 + 0.001)]
+        for k in (1, 2):
+            out.append(h.infer(frames[k], T0 + k / 30, T0 + k / 30 + 0.001))
+        h.close()
+        return out
+    a, b = run(True), run(False)
+    for (a2, a3), (b2, b3) in zip(a, b):
+        assert np.array_equal(a2, b2) and np.array_equal(a3, b3)

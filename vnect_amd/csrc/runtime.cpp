@@ -1342,27 +1342,31 @@ int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int 
 
 // Warm start: a tracking loop wants its FIRST frames at steady-state speed, but the first ~25 frames behind vnect_finalize run 1.5-3 %
 // slower (shader clocks ramp up from idle, instruction and translation caches are cold -- measured).  So finalize runs
-// the launch plan a few times on a grey 368 x 368 frame in slot 0 (every lane once more, three in flight), then restores the state a fresh
+// the launch plan a few times on a grey 368 x 368 frame in an empty slot (every lane once more, three in flight), then restores the state a fresh
 // handle has: empty slot, new filters, no timestamps.  VNECT_PRIME_FRAMES overrides the count (0 = off).  ~25 ms at start-up.
 int prime(vnect_handle* h)
 {
-    static const int n_env = getenv("VNECT_PRIME_FRAMES") ? atoi(getenv("VNECT_PRIME_FRAMES")) : 24;
-    if (n_env <= 0 || h->sharded || h->slots.empty() || (size_t)BOX * BOX * 3 > (size_t)h->cfg.max_frame_bytes) return VNECT_OK;
-    HIPCK(h, hipMemsetAsync(h->frames, 128, (size_t)BOX * BOX * 3, h->st));
+    const int n_env = getenv("VNECT_PRIME_FRAMES") ? atoi(getenv("VNECT_PRIME_FRAMES")) : 24;  // (read per call: a test flips it inside one process)
+    if (n_env <= 0 || h->sharded || (size_t)BOX * BOX * 3 > (size_t)h->cfg.max_frame_bytes) return VNECT_OK;
+    int ps = -1;  // an EMPTY frame slot (a caller may have uploaded frames before vnect_finalize: those are not touched)
+    for (size_t i = 0; i < h->slots.size() && ps < 0; i++)
+        if (h->slots[i].H == 0) ps = (int)i;
+    if (ps < 0) return VNECT_OK;
+    HIPCK(h, hipMemsetAsync(h->frames + (size_t)ps * h->cfg.max_frame_bytes, 128, (size_t)BOX * BOX * 3, h->st));
     HIPCK(h, hipStreamSynchronize(h->st));
-    h->slots[0].H = BOX, h->slots[0].W = BOX, h->slots[0].stride = (long long)BOX * 3;
+    h->slots[ps].H = BOX, h->slots[ps].W = BOX, h->slots[ps].stride = (long long)BOX * 3;
     int rc = VNECT_OK, ring = 0;
     double t = 1.0;
     for (int i = 0; i < n_env && !rc; i++, t += 1.0) {
-        rc = enqueue_frame(h, 0, t, t, &ring);
+        rc = enqueue_frame(h, ps, t, t, &ring);
         if (!rc) rc = collect_impl(h, nullptr, nullptr);
     }
     for (int rep = 0; rep < 2 && !rc && !h->twins.empty(); rep++) {  // the other lanes: as many frames in flight as there are lanes
         const int depth = (int)h->twins.size() + 1;
-        for (int i = 0; i < depth && !rc; i++, t += 1.0) rc = enqueue_frame(h, 0, t, t, &ring);
+        for (int i = 0; i < depth && !rc; i++, t += 1.0) rc = enqueue_frame(h, ps, t, t, &ring);
         for (int i = 0; i < depth && !rc; i++) rc = collect_impl(h, nullptr, nullptr);
     }
-    h->slots[0] = vnect_handle::SlotInfo();
+    h->slots[ps] = vnect_handle::SlotInfo();
     if (!rc) rc = reset_filters_impl(h);
     for (int s = 0; s < VNECT_MAX_STREAMS; s++) h->stream_seq[s] = -1, h->stream_lane[s] = nullptr;
     h->fp_dev_valid = false;  // (the next frame uploads its own geometry)
