@@ -277,10 +277,9 @@ int build_scale_tables(vnect_handle* h)
     HIPCK(h, hipMemcpy(h->d_stabs, &st, sizeof st, hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_mtabs, &mt, sizeof mt, hipMemcpyHostToDevice));
     h->stabs_host = st;
-    for (vnect_handle* q : std::vector<vnect_handle*>(1, h)) {  // (lanes share d_stabs; their eligibility follows lane 0's below)
-        if (q->stem_mode == 2) q->stem_frame_ok = plan::stem_frame_fits(st, q->stem.S, q->stem.scale_base, q->stem.groups, q->stem.row0, q->bf16);
-    }
-    for (vnect_handle* tw : h->twins) tw->stem_frame_ok = h->stem_frame_ok;
+    // the stem's from-the-frame form: do all tiles' frame rectangles still fit its LDS scratch at these scales?  (lanes share the tables)
+    if (h->stem_mode == 2) h->stem_frame_ok = plan::stem_frame_fits(st, h->stem.S, h->stem.scale_base, h->stem.groups, h->stem.row0, h->bf16);
+    for (vnect_handle* tw : h->twins) tw->stabs_host = st, tw->stem_frame_ok = h->stem_frame_ok;
     return VNECT_OK;
 }
 
@@ -545,8 +544,8 @@ void setup_stem(vnect_handle* h)
     a.S = h->Snet, a.scale_base = h->sharded ? h->cfg.pyramid_rank : 0, a.bf16 = h->bf16;
     // row groups of 4 and 5 pooled rows (hostplan.h)
     a.groups = plan::stem_groups(a.S, a.row0);
-    const vnect_handle* tabs_owner = h;  // a lane's tables are lane 0's: build_twin copies stabs_host before calling this
-    h->stem_frame_ok = h->stem_mode == 2 && plan::stem_frame_fits(tabs_owner->stabs_host, a.S, a.scale_base, a.groups, a.row0, h->bf16);
+    // (a lane's tables are lane 0's: build_twin copies stabs_host before calling this)
+    h->stem_frame_ok = h->stem_mode == 2 && plan::stem_frame_fits(h->stabs_host, a.S, a.scale_base, a.groups, a.row0, h->bf16);
 }
 
 int finalize_impl(vnect_handle* h)
