@@ -542,7 +542,7 @@ def test_pipelined_submit_collect_equals_sequential(weights, lanes, graph):
     a.close(), b.close()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_split"])
 def test_soak_three_lanes_deterministic(weights, prec):
     """Race detector: 3 000 frames of one stream, three in flight on three lanes, twice, and once frame by frame -- all
     three result sequences must be identical bit for bit (the K-group hand-off through LDS, the lane events, the result
@@ -550,7 +550,7 @@ def test_soak_three_lanes_deterministic(weights, prec):
     from tests import helpers
     frames = [helpers.synth_frame(40 + k, smooth=(k % 2 == 0)) for k in range(8)]
     h = _handle(BASELINE_SCALES, weights, lanes=3, num_frame_slots=8,
-                precision=_native().BF16 if prec == "bf16" else _native().FP32)
+                precision={"bf16": _native().BF16, "fp32_split": _native().FP32_SPLIT}.get(prec, _native().FP32))
     for k, f in enumerate(frames):
         h.upload_frame(k, f)
     n = 3000
