@@ -955,3 +955,28 @@ def test_split_product_path_meets_the_fp32_gates(weights, oracle_net):
         e2e.check(frame, t, t + 0.001, j2, j3, arena.activation("res5c_branch2c"), (H, W))
     print("split-product path: legal arg-max ties %d, worst 3-D excess over tolerance %.3g" % (e2e.ties, e2e.worst3))
     arena.close()
+
+
+def test_split_product_path_vs_float64(weights):
+    """Is the split-product path "reduced precision"?  Both GPU paths against the TRUE result: the torch float64 restatement of the
+    graph (tests/torch_net.py, independent of the C oracle) on one image.  The split-product maps must be as close to float64 as the
+    fp32 instruction's are (within 1.5x of its max error and of its RMS error), and both far inside the fp32 gate."""
+    import oracle
+    import torch
+    from tests import helpers, torch_net
+    n = _native()
+    torch.set_num_threads(16)
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(4242, smooth=True), [1.0])
+    with torch.inference_mode():
+        ref = torch_net.forward(weights, batch, dtype=torch.float64).numpy()
+    top = float(np.abs(ref).max())
+    errs = {}
+    for name, prec in (("fp32 instruction", n.FP32), ("split product", n.FP32_SPLIT)):
+        h = _handle([1.0], weights, precision=prec)
+        d = h.forward(batch).astype(np.float64) - ref
+        h.close()
+        errs[name] = (float(np.abs(d).max()) / top, float(np.sqrt((d * d).mean())) / top)
+        print("%-18s vs float64: max %.3g  rms %.3g (of max|map|)" % (name, *errs[name]))
+    f, s = errs["fp32 instruction"], errs["split product"]
+    assert s[0] <= 1.5 * f[0] and s[1] <= 1.5 * f[1], errs
+    assert s[0] <= 2e-5 and f[0] <= 2e-5
