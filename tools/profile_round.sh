@@ -6,6 +6,9 @@
 # Usage: tools/profile_round.sh r01
 R=${1:-r01}
 export TMPDIR=/tmp
+# the statistics describe the measured loop: without the warm-start frames of vnect_finalize (24 + 6 per handle), a profiled run is the
+# 10 warm-up + 100 timed frames of the product kernels + 25 frames of the profiling twin, as in rounds 1 and 2
+export VNECT_PRIME_FRAMES=0
 OUT=$PWD/gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
 # --no-aux: the auxiliary legs of bench.py overlap frames on purpose; the statistics here describe the synchronous headline loop
