@@ -83,6 +83,8 @@ def cpu_framework_baseline(weights, budget_s):
     # warm-up frame), then the sample on the fastest
     sweep, clk = {}, 1.0
     for th in sorted({t for t in (8, 16, 32, 64, 128, ncores) if t <= ncores}):
+        if sweep and (th > 128 or sweep[max(sweep)] < 0.5 * max(sweep.values())):
+            break  # past the knee: on the GPU boxes (a 16-core share of 256 visible cores) 128 threads run at 2 frames/s and 256 at 0.03
         torch.set_num_threads(th)
         clk += 1
         frame(0, clk)

@@ -352,3 +352,33 @@ def test_warm_start_leaves_a_fresh_handle(weights):
     a, b = run(True), run(False)
     for (a2, a3), (b2, b3) in zip(a, b):
         assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+
+
+# ------------------------------------------------------------------------------------------ the bench line's contract
+def test_bench_line_contract():
+    """`python bench.py` as the driver runs it (N = 1): ONE JSON line on stdout with the contract's keys -- metric / value / unit /
+    n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload -- plus the
+    `roofline` and `cpu_baseline` objects, the bf16 and split-product legs, and the evidence of what ran (ranks, backend)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-seconds", "1.5"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("frames/sec") and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"] and 300 < d["value"] < 5000
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["h2d_in_timed_region"] is False
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.2 < rf["frac"] < 1.0 and rf["launches_per_frame"] == 45 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["bf16"]["dtype"] == "bf16" and d["bf16"]["value"] > d["value"] and d["bf16"]["roofline"]["bound"] == "hbm"
+    assert d["fp32_split"]["value"] > 0 and d["fp32_split"]["roofline"]["bound"] == "mfma"
+    assert d["rccl_ranks"] == 1 and d["ranks"][0]["device"] == 0 and d["launched_by"] == "single process"
