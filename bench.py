@@ -297,6 +297,11 @@ def main():
         h.finalize()
         return h
 
+    # replicas: one synthetic video stream per rank, seeds 1234 + 1000*stream (BASELINE.md section 3);
+    # pyramid: every rank sees the SAME stream 0.  (Synthesised BEFORE the handle is built, so that nothing but the frame uploads lies
+    # between vnect_finalize's warm start and the measured loop.)
+    stream = 0 if args.pyramid else rank
+    host_frames = [helpers.synth_frame(stream_seed(stream, k)) for k in range(nslots)]
     graph_mode = False if args.no_graph else (True if args.graph else "auto")
     job = None
     rehearsal_note = None
@@ -319,10 +324,6 @@ def main():
     else:
         # lanes=3: the extra lanes only ever run frames submitted while others are in flight (the pipelined leg below)
         h = make(args.precision, use_graph=graph_mode, lanes=3)
-    # replicas: one synthetic video stream per rank, seeds 1234 + 1000*stream (BASELINE.md section 3);
-    # pyramid: every rank sees the SAME stream 0
-    stream = 0 if args.pyramid else rank
-    host_frames = [helpers.synth_frame(stream_seed(stream, k)) for k in range(nslots)]
     for k in range(nslots):
         h.upload_frame(k, host_frames[k])
 
