@@ -174,6 +174,31 @@ def test_fused_stem_is_bit_identical(weights, monkeypatch, prec):
     a.close(), b.close()
 
 
+def test_fused_stem_fuzz_frame_shapes_and_scales(weights, monkeypatch):
+    """The from-the-frame stem against the three stand-alone kernels on a sweep of frame shapes whose long side is 368 (its fast path:
+    odd widths and heights, so frame rows start at every byte alignment; black bars left / right or top / bottom) and of scale sets
+    (1 to 4 scales down to 0.5, incl. a scale whose size rounds back to 368): the final maps and the joints must be EQUAL."""
+    from tests import helpers
+    rng = np.random.RandomState(2024)
+    shapes = [(368, 368), (368, 1), (1, 368), (368, 367), (367, 368), (368, 123), (77, 368), (368, 245), (201, 368)]
+    scale_sets = [[1.0], [1.0, 0.8, 0.6], [1, 0.85, 0.7], [1.0, 0.9999], [1.0, 0.93, 0.71, 0.5], [0.9, 0.55]]
+    for si, scales in enumerate(scale_sets):
+        monkeypatch.setenv("VNECT_NO_STEM", "1")
+        ref = _handle(scales, weights)
+        monkeypatch.delenv("VNECT_NO_STEM")
+        fused = _handle(scales, weights)
+        for k in rng.choice(len(shapes), 4, replace=False):
+            H, W = shapes[k]
+            frame = helpers.synth_frame(5000 + 17 * si + int(k), H, W, smooth=bool((si + k) % 2))
+            t = T0 + 2000 + si * 10 + int(k)
+            fused.reset_filters(), ref.reset_filters()
+            a2, a3 = fused.infer(frame, t, t + 0.001)
+            b2, b3 = ref.infer(frame, t, t + 0.001)
+            assert np.array_equal(fused.activation("res5c_branch2c"), ref.activation("res5c_branch2c")), (scales, H, W)
+            assert np.array_equal(a2, b2) and np.array_equal(a3, b3), (scales, H, W)
+        fused.close(), ref.close()
+
+
 def test_conv_stack_batch_independent(h3, oracle_net):
     """The S images are independent: permuting the batch permutes the output (what sharding relies on)."""
     import oracle
