@@ -263,6 +263,29 @@ def test_no_exception_crosses_the_abi(weights):
 
 
 # ------------------------------------------------------------------------------------------ several streams on one handle
+@pytest.mark.parametrize("two_launches", [False, True])
+def test_reassigned_scales_equal_a_fresh_estimator(weights, monkeypatch, two_launches):
+    """`estimator.scales = [...]` (a plain attribute in the reference, estimator.py:32) re-plans pyramid and merge on a live
+    handle: the frames after it are bit-identical to a new estimator made with those scales.  The merge geometry is a by-value
+    kernel argument, so the two-launch form of the post-processing (VNECT_NO_POST_MERGE=1), whose arg-max launch sits inside the
+    captured graph, has to capture again -- both forms are run."""
+    from tests import helpers
+    if two_launches:
+        monkeypatch.setenv("VNECT_NO_POST_MERGE", "1")
+    frames = [np.ascontiguousarray(helpers.synth_frame(300 + k, 300, 420, smooth=True)) for k in range(4)]
+    live = _est(weights, scales=[1.0, 0.85, 0.7])
+    for k in range(2):
+        live(frames[k], timestamp=T0 + k / 30)
+    live.scales = BASELINE_SCALES
+    live.handle.reset_filters()
+    fresh = _est(weights, scales=BASELINE_SCALES)
+    for k, f in enumerate(frames):
+        a2, a3 = live(f, timestamp=T0 + 10 + k / 30)
+        b2, b3 = fresh(f, timestamp=T0 + 10 + k / 30)
+        assert np.array_equal(a2, b2) and np.array_equal(a3, b3), k
+    live.close(), fresh.close()
+
+
 def test_streams_on_one_handle_equal_handles_of_their_own(weights):
     """vnect_submit_stream: three independent videos (different frames, crop sizes, timestamps, irregular interleaving) served by
     ONE handle with three lanes -- one weight copy, a filter bank per stream -- must return, for every frame of every stream,

@@ -30,6 +30,8 @@ def hp():
     L.hp_resize_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, u8p, i32p, i32p]
     L.hp_gen_input_batch.argtypes = [u8p, C.c_int, C.c_int, C.c_int64, f64p, C.c_int, f32p, f64p, i32p, i32p, C.c_char_p, C.c_int]
     L.hp_merge.argtypes = [f32p, f64p, C.c_int, f64p]
+    L.hp_merge_geo.argtypes = [f32p, f64p, C.c_int, f64p]
+    L.hp_axis_mismatches.argtypes = [C.c_int, C.c_int, C.c_double]
     L.hp_extract_2d.argtypes = [f64p, C.c_int, f64p]
     L.hp_squarify.argtypes = [C.c_int, C.c_int, f64p, i32p, i32p, i32p, i32p, i32p, C.c_char_p, C.c_int]
     L.hp_pack_conv.argtypes = [f32p] + [C.c_int] * 9 + [f32p]
@@ -118,6 +120,29 @@ def test_merge_and_upsample_tables_vs_oracle(hp):
         j = np.empty((21, 2), np.float64)
         assert hp.hp_extract_2d(_p(heat, f64p), 21, _p(j, f64p)) == 0
         assert np.array_equal(j, oracle.extract_2d(heat))
+
+
+def test_per_entry_axis_functions_equal_the_tables(hp):
+    """axis.h (what post.hip evaluates on the device since round 3: every tap and weight computed where it is used) against the
+    whole-table builders, entry by entry and bit by bit: the merge's resizes over a sweep of scales, the x8 upsample, and shapes with
+    the far-border single tap; then the merge evaluated without tables (MergeGeo, as the kernels get it) against the oracle."""
+    import oracle
+    from tests import helpers
+    for s in list(np.linspace(0.3, 1.0, 71)) + [0.85, 0.7, 0.6, 0.8, 1 / 3, 0.9999]:
+        f = 1.0 / s
+        ds = int(np.rint(46 * f))  # cv_round: round half to even, like np.rint
+        assert hp.hp_axis_mismatches(46, ds, 1.0 / f) == 0, s
+    assert hp.hp_axis_mismatches(46, 368, 1.0 / 8.0) == 0
+    for ssize, dsize in ((5, 17), (368, 294), (7, 7), (2, 9), (1, 4), (100, 3)):
+        assert hp.hp_axis_mismatches(ssize, dsize, ssize / dsize) == 0, (ssize, dsize)
+    for scales in ([1.0, 0.8, 0.6], [1, 0.85, 0.7], [1.0], [0.9, 0.75, 0.5, 0.45, 1.0]):
+        maps = helpers.synth_maps(78, len(scales))
+        want = oracle.merge_scales(maps, scales)
+        got = np.empty((46, 46, 84), np.float64)
+        s64 = np.array(scales, np.float64)
+        assert hp.hp_merge_geo(_p(maps, f32p), _p(s64, f64p), len(scales), _p(got, f64p)) == 0
+        for q in range(4):
+            assert np.array_equal(got[:, :, 21 * q:21 * q + 21], want[q]), (scales, q)
 
 
 # ------------------------------------------------------------------------------------------ weight packing

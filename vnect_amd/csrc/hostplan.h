@@ -158,6 +158,17 @@ inline const char* build_merge_tab(double s, MergeTab* m)
     return nullptr;
 }
 
+// the same resize as the few numbers the device needs to rebuild any table entry itself (tables.h: MergeGeo; axis.h: axis_x_at / axis_y_at)
+inline const char* build_merge_geo(double s, MergeGeo* g, int i)
+{
+    MergeTab m;
+    if (const char* why = build_merge_tab(s, &m)) return why;
+    const double f = 1.0 / s;
+    const int ds = cv_round(HM * f);
+    g->scale[i] = 1.0 / f, g->off[i] = ds / 2 - HM / 2, g->copy[i] = ds == HM;
+    return nullptr;
+}
+
 // utils.py:169-171: cv2.resize(hm (46,46) f64, fx=fy=8) -> 368x368.  Returns false if the table does not have the (segment, phase)
 // row structure heat_argmax_kernel relies on.
 inline bool build_up_tab(UpTab* u)

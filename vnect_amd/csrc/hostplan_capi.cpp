@@ -9,6 +9,7 @@
 
 #include <vector>
 
+#include "axis.h"
 #include "hostplan.h"
 
 using namespace vnect;
@@ -95,6 +96,51 @@ int hp_merge(const float* maps, const double* scales, int S, double* out)
                 out[((size_t)r * HM + c) * MAPC + ch] = acc / (double)S;
             }
     return 0;
+}
+
+// the same merge the way post.hip evaluates it since round 3: no tables, every tap and weight from axis.h's per-entry functions and
+// the MergeGeo the runtime passes to the kernels
+int hp_merge_geo(const float* maps, const double* scales, int S, double* out)
+{
+    if (S < 1 || S > 8) return -1;
+    std::vector<MergeGeo> gv(1);
+    MergeGeo& g = gv[0];
+    memset(&g, 0, sizeof g);
+    g.S = S;
+    for (int i = 0; i < S; i++)
+        if (plan::build_merge_geo(scales[i], &g, i)) return -1;
+    for (int r = 0; r < HM; r++)
+        for (int c = 0; c < HM; c++)
+            for (int ch = 0; ch < MAPC; ch++) {
+                double acc = 0.0;
+                for (int i = 0; i < S; i++) {
+                    const AxE X = axis_x_at(c + g.off[i], HM, g.scale[i]), Y = axis_y_at(r + g.off[i], HM, g.scale[i]);
+                    const float* M = maps + (size_t)i * HM * HM * MAPC + ch;
+                    const float p00 = M[((size_t)Y.s0 * HM + X.s0) * MAPC], p01 = M[((size_t)Y.s0 * HM + X.s1) * MAPC];
+                    const float p10 = M[((size_t)Y.s1 * HM + X.s0) * MAPC], p11 = M[((size_t)Y.s1 * HM + X.s1) * MAPC];
+                    const float a1 = X.f, a0 = 1.f - a1, b1 = Y.f, b0 = 1.f - b1;
+                    const float r0 = X.edge ? p00 : p00 * a0 + p01 * a1;
+                    const float r1 = X.edge ? p10 : p10 * a0 + p11 * a1;
+                    const float v = g.copy[i] ? p00 : r0 * b0 + r1 * b1;
+                    acc += (double)v;
+                }
+                out[((size_t)r * HM + c) * MAPC + ch] = acc / (double)S;
+            }
+    return 0;
+}
+
+// axis.h's per-entry functions against the whole-table builders (hostplan.h: axis_x / axis_y), entry by entry: the number of
+// differing entries (taps, edge flag, weight bits) over both axes
+int hp_axis_mismatches(int ssize, int dsize, double scale)
+{
+    const plan::AxisTab x = plan::axis_x(ssize, dsize, scale), y = plan::axis_y(ssize, dsize, scale);
+    int bad = 0;
+    for (int d = 0; d < dsize; d++) {
+        const AxE ex = axis_x_at(d, ssize, scale), ey = axis_y_at(d, ssize, scale);
+        bad += ex.s0 != x.s0[d] || ex.s1 != x.s1[d] || ex.edge != x.edge[d] || memcmp(&ex.f, &x.f[d], 4) != 0;
+        bad += ey.s0 != y.s0[d] || ey.s1 != y.s1[d] || memcmp(&ey.f, &y.f[d], 4) != 0;
+    }
+    return bad;
 }
 
 // utils.extract_2d_joints (utils.py:153-175) through build_up_tab: heat (46,46,nj) float64 -> joints (nj,2) [row, col]

@@ -164,12 +164,12 @@ struct JointsOut {
 
 // merge + arg-max + joints in ONE launch: the last of the 168 arg-max workgroups (agent-scope ticket, zero between launches) runs the
 // joints stage
-hipError_t launch_post(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, unsigned* ticket,
+hipError_t launch_post(const float* maps, MergeGeo geo, ArgPartial* part, unsigned* ticket,
                        FilterBank* fb, const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st);
 // multi-scale merge of the heat-maps (in LDS, the rows each workgroup needs) + arg-max of the virtual x8 upsample
-hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st);
+hipError_t launch_argmax(const float* maps, MergeGeo geo, ArgPartial* part, hipStream_t st);
 // out may be (device-mapped) pinned HOST memory: the kernel's 21x2 + 21x3 results then need no device-to-host copy
-hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
+hipError_t launch_joints(const ArgPartial* part, const float* maps, MergeGeo geo, FilterBank* fb,
                          const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st);
 
 // ---- pyramid sharding: the exchange by peer writes (SURVEY 8e "plain peer writes ... into the gather buffer") -----------

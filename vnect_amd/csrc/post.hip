@@ -4,6 +4,7 @@
 // src/utils.py:13-21,58-79,153-219 and src/OneEuroFilter.py:13-75, so results are bit-identical to it.
 #include "kernels.h"
 #include "pyramid.h"
+#include "axis.h"  // axis_x_at / axis_y_at: one entry of cv2.resize's per-axis tables, computed where it is used
 
 #include <stddef.h>
 
@@ -39,50 +40,42 @@ hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* 
 // ---------------------------------------------------------------------------------------------
 // estimator.py:105-129: one cell of a merged map,
 //   avg_q[r][c][j] = (1/S) * sum_i crop(cv2.resize(map_i_q, fx=fy=1/s_i))[r][c][j]   (f32 interpolation, f64 sum)
-// evaluated on demand: the four 46x46x21 f64 averages of the reference are never materialised.
+// evaluated on demand: the four 46x46x21 f64 averages of the reference are never materialised.  Round 3: the taps and weights are
+// computed here (axis.h) from the geometry in the kernel arguments -- the kernels used to stage 4 KB of merge tables into LDS and
+// load the x8 upsample's columns from global memory before they could request the first map value; now that request comes first.
 // SMAX: compile-time bound of the scale loops (3 covers the reference's and BASELINE's pyramids; these kernels run their
 // code once, cold, so its size is their time: the 8-scale form is twice as long)
 template <int SMAX>
-__device__ __forceinline__ double merged_cell(const float* __restrict__ maps, const MergeTabs* __restrict__ tabs, int S,
-                                              int ch, int r, int c)
+__device__ __forceinline__ double merged_cell(const float* __restrict__ maps, const MergeGeo& geo, int ch, int r, int c)
 {
     // All taps of all scales are requested before any is used (no load sits behind a data-dependent branch), so a
     // thread pays one memory round trip, not one per scale.  For a scale that is a plain copy (size unchanged) the
-    // tables are the identity: tap (sy0[r], sx[c]) IS element (r, c).
+    // entries are the identity: tap (s0(r), s0(c)) IS element (r, c).
+    const int S = geo.S;
     float p00[SMAX], p01[SMAX], p10[SMAX], p11[SMAX];
+    AxE X[SMAX], Y[SMAX];
 #pragma unroll
     for (int i = 0; i < SMAX; i++) {
         if (i < S) {
-            const MergeTab& mt = tabs->t[i];
+            X[i] = axis_x_at(c + geo.off[i], HM, geo.scale[i]), Y[i] = axis_y_at(r + geo.off[i], HM, geo.scale[i]);
             const float* M = maps + (long long)i * HM * HM * MAPC + ch;
-            const int sx = mt.sx[c], sx1 = sx + 1 < HM ? sx + 1 : HM - 1;
-            const float* R0 = M + (long long)mt.sy0[r] * HM * MAPC;
-            const float* R1 = M + (long long)mt.sy1[r] * HM * MAPC;
-            p00[i] = R0[sx * MAPC], p01[i] = R0[sx1 * MAPC], p10[i] = R1[sx * MAPC], p11[i] = R1[sx1 * MAPC];
+            const float* R0 = M + (long long)Y[i].s0 * HM * MAPC;
+            const float* R1 = M + (long long)Y[i].s1 * HM * MAPC;
+            p00[i] = R0[X[i].s0 * MAPC], p01[i] = R0[X[i].s1 * MAPC], p10[i] = R1[X[i].s0 * MAPC], p11[i] = R1[X[i].s1 * MAPC];
         }
     }
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < SMAX; i++) {
         if (i < S) {
-            const MergeTab& mt = tabs->t[i];
-            const float a0 = mt.a0[c], a1 = mt.a1[c];
-            const float r0 = mt.edge[c] ? p00[i] : p00[i] * a0 + p01[i] * a1;
-            const float r1 = mt.edge[c] ? p10[i] : p10[i] * a0 + p11[i] * a1;
-            const float v = mt.copy ? p00[i] : r0 * mt.b0[r] + r1 * mt.b1[r];
+            const float a1 = X[i].f, a0 = 1.f - a1, b1 = Y[i].f, b0 = 1.f - b1;
+            const float r0 = X[i].edge ? p00[i] : p00[i] * a0 + p01[i] * a1;
+            const float r1 = X[i].edge ? p10[i] : p10[i] * a0 + p11[i] * a1;
+            const float v = geo.copy[i] ? p00[i] : r0 * b0 + r1 * b1;
             acc += (double)v;
         }
     }
     return acc / (double)S;
-}
-
-// the merge tables are read many times per thread: copy them to LDS once per workgroup
-__device__ __forceinline__ void stage_merge_tabs(const MergeTabs* __restrict__ g, MergeTabs* l, int S)
-{
-    const int words = (int)((offsetof(MergeTabs, t) + sizeof(MergeTab) * S) / 4);
-    const int* src = (const int*)g;
-    int* dst = (int*)l;
-    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -109,23 +102,18 @@ __device__ __forceinline__ void wave_argmax(double& v, int& i)
     }
 }
 
-// `smt`: the merge tables in LDS (staged by the caller, visible after this function's first barrier).
 template <int SMAX>
-__device__ __forceinline__ void argmax_body(const float* __restrict__ maps, const MergeTabs* smt, int S,
-                                            const UpTab* __restrict__ up, ArgPartial* __restrict__ part)
+__device__ __forceinline__ void argmax_body(const float* __restrict__ maps, const MergeGeo& geo, ArgPartial* __restrict__ part)
 {
     __shared__ double map[HM * HM];
     __shared__ double wv[ARG_THREADS / 64];
     __shared__ int wi[ARG_THREADS / 64];
-    __shared__ double tb0[16], tb1[16];  // the 8 row phases (rows 4..11 of the table)
     const int j = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
-    if (tid < 16) tb0[tid] = up->b0[tid], tb1[tid] = up->b1[tid];
-    // this thread's column of the x8 upsample: requested NOW, in flight behind the merge (none of it depends on the merge; left
-    // behind the barrier it was one more memory round trip on the kernel's critical path)
+    // this thread's column of the x8 upsample (utils.py:169-171: cv2.resize(hm f64, fx=fy=8); hostplan.h: build_up_tab)
     const int x = tid, xc = x < BOX ? x : BOX - 1;
-    const int sx = up->sx[xc], edge = up->edge[xc];
-    const double a0 = up->a0[xc], a1 = up->a1[xc];
-    __syncthreads();  // smt (and tb0 / tb1) visible
+    const AxE ux = axis_x_at(xc, HM, 1.0 / 8.0);
+    const int sx = ux.s0, edge = ux.edge;
+    const double a0 = (double)(1.f - ux.f), a1 = (double)ux.f;
     {   // the multi-scale merge (estimator.py:105-129) of exactly the heat-map rows this slab blends: at most 7 of the 46,
         // one cell per thread -- no separate merge launch, no f64 plane in HBM
         const int g0 = slab * ARG_SEGS, g1 = g0 + ARG_SEGS < 47 ? g0 + ARG_SEGS : 47;
@@ -133,19 +121,22 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
         const int cells = (r_hi - r_lo + 1) * HM;
         for (int p = tid; p < cells; p += ARG_THREADS) {
             const int r = r_lo + p / HM, c = p % HM;
-            map[r * HM + c] = merged_cell<SMAX>(maps, smt, S, j, r, c);
+            map[r * HM + c] = merged_cell<SMAX>(maps, geo, j, r, c);
         }
     }
     __syncthreads();
-    // Row structure of the x8 upsample (checked against the table on the host, build_up_table): destination row y
+    // Row structure of the x8 upsample (checked on the host when a handle is made, build_up_tab): destination row y
     // belongs to segment g = (y + 4) / 8 and phase p = (y + 4) % 8; it blends source rows max(g-1, 0) and min(g, 45)
-    // with weights b0[4 + p], b1[4 + p].  Segment 0 has phases 4..7 (rows 0..3), segment 46 phases 0..3 (rows 364..367).
+    // with the weights of row 4 + p.  Segment 0 has phases 4..7 (rows 0..3), segment 46 phases 0..3 (rows 364..367).
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
     if (x < BOX) {
         double w0[8], w1[8];
 #pragma unroll
-        for (int p = 0; p < 8; p++) w0[p] = tb0[4 + p], w1[p] = tb1[4 + p];
+        for (int p = 0; p < 8; p++) {
+            const float f = axis_y_at(4 + p, HM, 1.0 / 8.0).f;  // (folds to eight constants)
+            w0[p] = (double)(1.f - f), w1[p] = (double)f;
+        }
         auto hrow = [&](int sy) {
             const double* R = map + sy * HM;
             return edge ? R[sx] : R[sx] * a0 + R[sx + 1] * a1;
@@ -179,18 +170,14 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
 }
 template <int SMAX>
 __global__ __launch_bounds__(ARG_THREADS) void heat_argmax_kernel(const float* __restrict__ maps,
-                                                                  const MergeTabs* __restrict__ mtabs, int S,
-                                                                  const UpTab* __restrict__ up,
-                                                                  ArgPartial* __restrict__ part)
+                                                                  const MergeGeo geo, ArgPartial* __restrict__ part)
 {
-    __shared__ MergeTabs smt;
-    stage_merge_tabs(mtabs, &smt, S);
-    argmax_body<SMAX>(maps, &smt, S, up, part);
+    argmax_body<SMAX>(maps, geo, part);
 }
-hipError_t launch_argmax(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, hipStream_t st)
+hipError_t launch_argmax(const float* maps, MergeGeo geo, ArgPartial* part, hipStream_t st)
 {
-    if (S <= 3) hipLaunchKernelGGL(heat_argmax_kernel<3>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part);
-    else hipLaunchKernelGGL(heat_argmax_kernel<VNECT_MAX_S>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part);
+    if (geo.S <= 3) hipLaunchKernelGGL(heat_argmax_kernel<3>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, geo, part);
+    else hipLaunchKernelGGL(heat_argmax_kernel<VNECT_MAX_S>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, geo, part);
     return hipGetLastError();
 }
 
@@ -258,8 +245,7 @@ __device__ float oef_f32(Filt& f, float x, double t, int nep50)
 
 // utils.hm_pt_interp_bilinear (utils.py:58-79), scale 8, on merged map q (channel ch) evaluated cell by cell
 template <int SMAX>
-__device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S, int ch,
-                            double dst_y, double dst_x)
+__device__ double pt_interp(const float* __restrict__ maps, const MergeGeo& geo, int ch, double dst_y, double dst_x)
 {
     const double src_x = (dst_x + 0.5) / 8.0 - 0.5;
     const double src_y = (dst_y + 0.5) / 8.0 - 0.5;
@@ -268,8 +254,8 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
     y0 = y0 < 0 ? 0 : (y0 > HM - 1 ? HM - 1 : y0);  // keep NaN inputs from indexing outside the map
     const int x1 = x0 + 1 < HM - 1 ? x0 + 1 : HM - 1;
     const int y1 = y0 + 1 < HM - 1 ? y0 + 1 : HM - 1;
-    const double m00 = merged_cell<SMAX>(maps, mtabs, S, ch, y0, x0), m01 = merged_cell<SMAX>(maps, mtabs, S, ch, y0, x1);
-    const double m10 = merged_cell<SMAX>(maps, mtabs, S, ch, y1, x0), m11 = merged_cell<SMAX>(maps, mtabs, S, ch, y1, x1);
+    const double m00 = merged_cell<SMAX>(maps, geo, ch, y0, x0), m01 = merged_cell<SMAX>(maps, geo, ch, y0, x1);
+    const double m10 = merged_cell<SMAX>(maps, geo, ch, y1, x0), m11 = merged_cell<SMAX>(maps, geo, ch, y1, x1);
     const double v0 = (x1 - src_x) * m00 + (src_x - x0) * m01;
     const double v1 = (x1 - src_x) * m10 + (src_x - x0) * m11;
     return (y1 - src_y) * v0 + (src_y - y0) * v1;
@@ -277,11 +263,10 @@ __device__ double pt_interp(const float* __restrict__ maps, const MergeTabs* __r
 
 // estimator.py:132-139 for all 21 joints in one workgroup, one thread per filter: 42 2-D filters, then 63 read-offs
 // (x/y/z maps merged on demand) + root subtraction + 63 3-D filters, then the un-mapping.
-// `smt`: the merge tables in LDS, staged (and made visible by a barrier) by the caller.  `f2` / `f3`: this thread's filter states,
-// loaded by the caller -- in post_kernel at the very start of EVERY workgroup, so that the one that turns out to be last does not
+// `f2` / `f3`: this thread's filter states, loaded by the caller -- in post_kernel at the very start of EVERY workgroup, so that the one that turns out to be last does not
 // start a memory round trip for them then.
 template <int SMAX>
-__device__ __forceinline__ void joints_body(const ArgPartial* part, const float* __restrict__ maps, const MergeTabs* smt, int S,
+__device__ __forceinline__ void joints_body(const ArgPartial* part, const float* __restrict__ maps, const MergeGeo& geo,
                                             FilterBank* fb, Filt& f2, Filt& f3, double scaler, double off, const FrameDyn& dyn,
                                             int nep50, JointsOut* __restrict__ out)
 {
@@ -310,7 +295,7 @@ __device__ __forceinline__ void joints_body(const ArgPartial* part, const float*
         fb->f2[j2][k2] = f2;
     }
     __syncthreads();
-    if (t < NJ * 3) p3[t] = (float)(pt_interp<SMAX>(maps, smt, S, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
+    if (t < NJ * 3) p3[t] = (float)(pt_interp<SMAX>(maps, geo, (k3 + 1) * NJ + j3, c2[j3 * 2], c2[j3 * 2 + 1]) * 100);
     __syncthreads();
     if (t < NJ * 3) {
         const float v = p3[t] - p3[14 * 3 + k3];  // joints_3d -= joints_3d[14, :] in float32
@@ -334,19 +319,16 @@ __device__ __forceinline__ void load_filters(const FilterBank* fb, const FramePa
 }
 template <int SMAX>
 __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restrict__ part, const float* __restrict__ maps,
-                                                     const MergeTabs* __restrict__ mtabs, int S, FilterBank* fb,
+                                                     const MergeGeo geo, FilterBank* fb,
                                                      const FrameParams* __restrict__ fp, const FrameDyn dyn, int nep50,
                                                      JointsOut* __restrict__ out)
 {
-    __shared__ MergeTabs smt;
-    // Every global read that does not depend on a computed value is requested up front (tables, both filter states, frame
+    // Every global read that does not depend on a computed value is requested up front (both filter states, frame
     // parameters; the partials at the top of joints_body): the kernel is one workgroup and is priced in memory round trips.
-    stage_merge_tabs(mtabs, &smt, S);
     Filt f2, f3;
     double scaler, off;
     load_filters(fb, fp, f2, f3, scaler, off);
-    __syncthreads();
-    joints_body<SMAX>(part, maps, &smt, S, fb, f2, f3, scaler, off, dyn, nep50, out);
+    joints_body<SMAX>(part, maps, geo, fb, f2, f3, scaler, off, dyn, nep50, out);
 }
 
 // Both in ONE launch (round 2): the 168 arg-max workgroups publish their partials write-through and take an agent-scope ticket; the
@@ -358,23 +340,20 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
 // pair instead (buffer_wbl2 sc1 / buffer_inv sc1) is priced at ~1.7 us EACH in the same guide, on the critical path of a kernel
 // that is nothing but a chain of round trips -- so the relaxed form stays, and this comment is what keeps it honest: any change
 // to the store / wait / add / load sequence must be checked against that table again.
-// Round 3: every workgroup requests what the joints stage needs that does not depend on the arg-max (merge tables -> LDS, which the
-// merge itself uses; the first 105 threads' filter states and un-mapping constants -> registers) before anything else, so the last
-// arriver starts no memory round trip for them; on a pyramid-sharded handle a frame whose exchange failed (dyn.xfail) skips the
+// Round 3: every workgroup requests what the joints stage needs that does not depend on the arg-max (the first 105 threads' filter
+// states and un-mapping constants -> registers) before anything else, so the last arriver starts no memory round trip for them;
+// the resize geometry travels in the kernel arguments (MergeGeo) and every table entry is computed where it is used; on a pyramid-sharded handle a frame whose exchange failed (dyn.xfail) skips the
 // joints stage -- the filter banks do not advance on stale maps -- and reports status 1.
 template <int SMAX>
-__global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restrict__ maps, const MergeTabs* __restrict__ mtabs, int S,
-                                                           const UpTab* __restrict__ up, ArgPartial* part, unsigned* ticket,
+__global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restrict__ maps, const MergeGeo geo, ArgPartial* part, unsigned* ticket,
                                                            FilterBank* fb, const FrameParams* __restrict__ fp, const FrameDyn dyn,
                                                            int nep50, JointsOut* __restrict__ out)
 {
-    __shared__ MergeTabs smt;
     __shared__ int last;
-    stage_merge_tabs(mtabs, &smt, S);
     Filt f2, f3;
     double scaler, off;
     load_filters(fb, fp, f2, f3, scaler, off);
-    argmax_body<SMAX>(maps, &smt, S, up, part);
+    argmax_body<SMAX>(maps, geo, part);
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's `sc1` stores of the partial have left (write-through)
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -387,20 +366,20 @@ __global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restri
         if (threadIdx.x == 0) out->status = 1;  // the exchange of THIS frame timed out: stale maps, leave the filters alone
         return;
     }
-    joints_body<SMAX>(part, maps, &smt, S, fb, f2, f3, scaler, off, dyn, nep50, out);
+    joints_body<SMAX>(part, maps, geo, fb, f2, f3, scaler, off, dyn, nep50, out);
 }
-hipError_t launch_post(const float* maps, const MergeTabs* mtabs, int S, const UpTab* up, ArgPartial* part, unsigned* ticket,
-                       FilterBank* fb, const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
+hipError_t launch_post(const float* maps, MergeGeo geo, ArgPartial* part, unsigned* ticket, FilterBank* fb, const FrameParams* fp,
+                       FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
 {
-    if (S <= 3) hipLaunchKernelGGL(post_kernel<3>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part, ticket, fb, fp, dyn, nep50, out);
-    else hipLaunchKernelGGL(post_kernel<VNECT_MAX_S>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, mtabs, S, up, part, ticket, fb, fp, dyn, nep50, out);
+    if (geo.S <= 3) hipLaunchKernelGGL(post_kernel<3>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, geo, part, ticket, fb, fp, dyn, nep50, out);
+    else hipLaunchKernelGGL(post_kernel<VNECT_MAX_S>, dim3(NJ, ARG_SLABS), dim3(ARG_THREADS), 0, st, maps, geo, part, ticket, fb, fp, dyn, nep50, out);
     return hipGetLastError();
 }
-hipError_t launch_joints(const ArgPartial* part, const float* maps, const MergeTabs* mtabs, int S, FilterBank* fb,
-                         const FrameParams* fp, FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)
+hipError_t launch_joints(const ArgPartial* part, const float* maps, MergeGeo geo, FilterBank* fb, const FrameParams* fp, FrameDyn dyn,
+                         int nep50, JointsOut* out, hipStream_t st)
 {
-    if (S <= 3) hipLaunchKernelGGL(joints_kernel<3>, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, dyn, nep50, out);
-    else hipLaunchKernelGGL(joints_kernel<VNECT_MAX_S>, dim3(1), dim3(128), 0, st, part, maps, mtabs, S, fb, fp, dyn, nep50, out);
+    if (geo.S <= 3) hipLaunchKernelGGL(joints_kernel<3>, dim3(1), dim3(128), 0, st, part, maps, geo, fb, fp, dyn, nep50, out);
+    else hipLaunchKernelGGL(joints_kernel<VNECT_MAX_S>, dim3(1), dim3(128), 0, st, part, maps, geo, fb, fp, dyn, nep50, out);
     return hipGetLastError();
 }
 

@@ -106,8 +106,7 @@ struct vnect_handle {
     bool fp_dev_valid = false;
     int fp_ring = 0;
     ScaleTabs* d_stabs = nullptr;
-    MergeTabs* d_mtabs = nullptr;
-    UpTab* d_up = nullptr;
+    MergeGeo mgeo{};  // the merge's resize geometry: passed to the post kernels by value, they compute table entries themselves
     ArgPartial* d_part = nullptr;
     unsigned* d_ticket = nullptr;  // post_kernel's arrival counter (zero between launches)
     bool post_merged = true;       // merge + arg-max + joints as ONE launch (post_kernel); false: two launches (VNECT_NO_POST_MERGE=1)
@@ -265,30 +264,30 @@ int build_scale_tables(vnect_handle* h)
 {
     ScaleTabs st;
     memset(&st, 0, sizeof st);
-    MergeTabs mt;
-    memset(&mt, 0, sizeof mt);
-    st.S = mt.S = h->S;
+    MergeGeo mg;
+    memset(&mg, 0, sizeof mg);
+    st.S = mg.S = h->S;
     plan::fill_lut(st.lut);
     for (int i = 0; i < h->S; i++) {
         const double s = h->cfg.scales[i];
         if (const char* why = plan::build_scale_tab(s, &st, i)) return fail(h, VNECT_E_ARG, why);
-        if (const char* why = plan::build_merge_tab(s, &mt.t[i])) return fail(h, VNECT_E_ARG, why);
+        if (const char* why = plan::build_merge_geo(s, &mg, i)) return fail(h, VNECT_E_ARG, why);
     }
     HIPCK(h, hipMemcpy(h->d_stabs, &st, sizeof st, hipMemcpyHostToDevice));
-    HIPCK(h, hipMemcpy(h->d_mtabs, &mt, sizeof mt, hipMemcpyHostToDevice));
+    h->mgeo = mg;
     h->stabs_host = st;
     // the stem's from-the-frame form: do all tiles' frame rectangles still fit its LDS scratch at these scales?  (lanes share the tables)
     if (h->stem_mode == 2) h->stem_frame_ok = plan::stem_frame_fits(st, h->stem.S, h->stem.scale_base, h->stem.groups, h->stem.row0, h->bf16);
-    for (vnect_handle* tw : h->twins) tw->stabs_host = st, tw->stem_frame_ok = h->stem_frame_ok;
+    for (vnect_handle* tw : h->twins) tw->stabs_host = st, tw->mgeo = mg, tw->stem_frame_ok = h->stem_frame_ok;
     return VNECT_OK;
 }
 
 int build_up_table(vnect_handle* h)
 {
     std::vector<UpTab> u(1);
-    // heat_argmax_kernel walks the rows by (segment, phase): plan::build_up_tab checks that the table really has that structure
+    // the arg-max kernels walk the rows of the x8 upsample by (segment, phase) and compute the entries themselves: plan::build_up_tab
+    // builds the full table with the same formulas and checks that it really has that structure
     if (!plan::build_up_tab(&u[0])) return fail(h, VNECT_E_STATE, "internal: x8 upsample table does not have the segment/phase structure");
-    HIPCK(h, hipMemcpy(h->d_up, u.data(), sizeof(UpTab), hipMemcpyHostToDevice));
     return VNECT_OK;
 }
 
@@ -907,7 +906,7 @@ int run_pre(vnect_handle* h, const FrameDyn& dyn, bool timed = false, bool want_
 int run_argmax(vnect_handle* h)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, launch_argmax(maps, h->d_mtabs, h->S, h->d_up, h->d_part, h->st));
+    HIPCK(h, launch_argmax(maps, h->mgeo, h->d_part, h->st));
     return VNECT_OK;
 }
 
@@ -915,7 +914,7 @@ int run_argmax(vnect_handle* h)
 int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out, int stream = 0)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, launch_joints(h->d_part, maps, h->d_mtabs, h->S, h->d_fb + stream, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
+    HIPCK(h, launch_joints(h->d_part, maps, h->mgeo, h->d_fb + stream, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
     return VNECT_OK;
 }
 
@@ -923,7 +922,7 @@ int run_joints(vnect_handle* h, const FrameDyn& dyn, JointsOut* out, int stream 
 int run_post(vnect_handle* h, const FrameDyn& dyn, JointsOut* out, int stream = 0)
 {
     const float* maps = h->sharded ? h->gather : h->tensors[h->t_out].d;
-    HIPCK(h, launch_post(maps, h->d_mtabs, h->S, h->d_up, h->d_part, h->d_ticket, h->d_fb + stream, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
+    HIPCK(h, launch_post(maps, h->mgeo, h->d_part, h->d_ticket, h->d_fb + stream, h->d_fp, dyn, h->cfg.numpy_promotion, out, h->st));
     return VNECT_OK;
 }
 
@@ -1119,7 +1118,7 @@ int build_twin(vnect_handle* h)
     t->cfg = h->cfg, t->S = h->S, t->Snet = h->Snet, t->bf16 = h->bf16, t->keep_activations = false;
     HIPCK(h, hipStreamCreateWithFlags(&t->st, hipStreamNonBlocking));
     // shared: read-only tables and frames; the filter bank (its users are chained by events)
-    t->frames = h->frames, t->d_stabs = h->d_stabs, t->d_mtabs = h->d_mtabs, t->d_up = h->d_up, t->d_fb = h->d_fb;
+    t->frames = h->frames, t->d_stabs = h->d_stabs, t->mgeo = h->mgeo, t->d_fb = h->d_fb;
     t->slots = h->slots;
     int rc;
     if ((rc = dev_alloc(t, &t->d_fp, 1))) return fail(h, rc, t->err);
@@ -1438,8 +1437,6 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         if (!pre && (rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes + 16))) return rc;  // + slack: a dword read may run 3 bytes past a frame's last pixel
         if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
-        if ((rc = dev_alloc(h, &h->d_mtabs, 1))) return rc;
-        if ((rc = dev_alloc(h, &h->d_up, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
         if ((rc = dev_alloc(h, &h->d_ticket, 4))) return rc;
         HIPCK(h, hipMemset(h->d_ticket, 0, 4 * sizeof(unsigned)));
@@ -1593,6 +1590,14 @@ int vnect_set_scales(vnect_handle* h, const double* scales, int n)
         if (rc) {
             memcpy(h->cfg.scales, old, sizeof old);
             build_scale_tables(h);
+        }
+        // the two-launch form of the post-processing (VNECT_NO_POST_MERGE=1) has its arg-max launch -- and with it the merge geometry,
+        // a by-value kernel argument -- inside the captured graph: capture again (the default form launches post_kernel eagerly)
+        if (h->finalized && !h->sharded && !h->post_merged && h->gexec) {
+            int rg = build_graph(h);
+            for (vnect_handle* t : h->twins)
+                if (!rg && (rg = build_graph(t))) fail(h, rg, t->err);
+            if (rg) return rg;
         }
         return rc;
     });

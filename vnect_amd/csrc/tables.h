@@ -44,9 +44,13 @@ struct MergeTab {  // cv2.resize(map, fx=fy=1/s) restricted to the 46x46 centre 
     int sy0[HM], sy1[HM];
     float b0[HM], b1[HM];
 };
-struct MergeTabs {
-    int S;
-    MergeTab t[8];
+// What the post-processing kernels need to rebuild a MergeTab entry on the fly (round 3: they compute the taps and weights from these few
+// numbers with axis.h's two functions, which tests/test_hostplan.py holds to the host's tables, instead of loading 4 KB of tables first): per scale the source
+// step of cv2.resize(map, fx = fy = 1 / s) as the host computed it, the centre crop's offset, and whether the resize is a plain copy.
+struct MergeGeo {
+    int S, pad_;
+    double scale[8];
+    int off[8], copy[8];
 };
 struct UpTab {  // x8 upsample tables (utils.extract_2d_joints)
     int sx[BOX], edge[BOX];
