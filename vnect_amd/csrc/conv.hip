@@ -234,6 +234,120 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The WIDE tail (round 3): the same fusion for a 3x3 layer with 128 output channels -- res3*_branch2b -> res3*_branch2c (+ shortcut,
+// ReLU; vnect_model.py:62-103) and the head's res5c_branch2b -> res5c_branch2c (the final maps; vnect_model.py:211-217).  The 3x3 layer
+// runs on 32 x 128 tiles (conv_stream_kernel<32, 128, 1, ...>: four consumer waves side by side over N, the same number of
+// workgroups and the same MFMA work per wave as the 64 x 64 plan's 200 tiles), so a workgroup owns ALL 128 channels of its 32 pixels;
+// relu(acc + bias) goes to LDS as a 32 x 128 tile and the 1x1 layer is a second GEMM with K = 128 over tail_n / 32 column blocks:
+// tail wave tw (the four producer waves first -- they hold their first block's weight fragments and both blocks' shortcut values in
+// registers since before the K loop -- then the four consumer waves) takes blocks tw, tw + 8.  Every output accumulates its 128
+// products in the order the stand-alone layer does (chunk by chunk, unit by unit, the same MFMA instruction), from the values that
+// layer would read back from HBM: bit-identical to the two launches.  These instantiations may use 256 VGPRs (their 100-KB ring admits
+// one workgroup per CU anyway), so a wave keeps all of its A fragments (64 registers in fp32) across its blocks.
+#ifndef WT_DBG
+#define WT_DBG 0  // timing probes of the wide tail (wrong results): 1 = 1 / NQ of the MFMAs, 2 = no stores, 3 = one weight load per block
+#endif
+template <bool BF>
+constexpr int WIDE_MS = BF ? 136 : 132;  // mid row stride in elements: 272 B (bf16) / 528 B (fp32), conflict-free 16-byte reads
+template <bool BF>
+struct WideRegs {
+    static constexpr int NQ = BF ? 8 : 16;  // MFMA groups over K = 128
+    unsigned rw[2][16];                      // shortcut values of this wave's two blocks, as loaded
+    f32x4 Bf[2][NQ];                         // weight fragments of both blocks
+};
+template <bool BF>
+__device__ __forceinline__ void wide_load_b(const ConvArgs& a, int cb, int lane, f32x4 (&Bf)[WideRegs<BF>::NQ])
+{
+    // tail_w is packed in fragment order (hostplan.h: pack_tail_wide): [block][q][lane] x 16 bytes -- one contiguous KiB per instruction
+    typedef __attribute__((address_space(1))) const f32x4 cgf4;
+    constexpr int NQ = WideRegs<BF>::NQ;
+    cgf4* bp = (cgf4*)a.tail_w + cb * (NQ * 64) + lane;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) Bf[q] = bp[(WT_DBG == 3 ? 0 : q) * 64];
+}
+// the shortcut values of a tail wave's blocks (any wave can request them before the K loop: 32 registers) ...
+template <bool BF>
+__device__ __forceinline__ void wide_load_resid(const ConvArgs& a, int m0, int tw, int lane, WideRegs<BF>& T)
+{
+    const int nb = (a.tail_n + 31) >> 5, mb = m0 + 4 * (lane >> 5);
+    if (!a.resid) return;
+    if (tw < nb) tail_load_resid<BF>(a, mb, tw, lane, T.rw[0]);
+    if (tw + 8 < nb) tail_load_resid<BF>(a, mb, tw + 8, lane, T.rw[1]);
+}
+// ... and the weight fragments (a producer wave before the K loop -- it has the registers --, a consumer wave behind it)
+template <bool BF>
+__device__ __forceinline__ void wide_load_weights(const ConvArgs& a, int tw, int lane, WideRegs<BF>& T)
+{
+    const int nb = (a.tail_n + 31) >> 5;
+    if (tw < nb) wide_load_b<BF>(a, tw, lane, T.Bf[0]);
+    if (tw + 8 < nb) wide_load_b<BF>(a, tw + 8, lane, T.Bf[1]);
+}
+// Everything a wave's tail needs from memory has been requested by now (T); its two blocks' MFMA chains are independent and run
+// interleaved, every A fragment (one 16-byte LDS read) feeding both.  The two tail waves of a SIMD -- one producer, one consumer
+// wave -- share its matrix pipe: the producer's operands are in registers when the K loop ends, so its MFMAs cover the consumer's
+// wait for its weight fragments.
+template <bool BF>
+__device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, int m0, int tw, int lane, WideRegs<BF>& T)
+{
+    constexpr int MS = WIDE_MS<BF>, NQ = WideRegs<BF>::NQ;
+    constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4;
+    const int nb = (a.tail_n + 31) >> 5;
+    if (tw >= nb) return;
+    const bool two = tw + 8 < nb;  // (wave-uniform)
+    const int col = lane & 31, hh = lane >> 5;
+    const int mb = m0 + 4 * hh;  // C/D map: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float bias0 = ((cgfloat*)a.tail_bias)[tw * 32 + col], bias1 = two ? ((cgfloat*)a.tail_bias)[(tw + 8) * 32 + col] : 0.f;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc0[r] = 0.f, acc1[r] = 0.f;
+    auto afrag = [&](int q) __attribute__((always_inline)) {
+        if constexpr (BF) return *(const f32x4*)((const __bf16*)smem + col * MS + UQ * q + UH * hh);
+        else return *(const f32x4*)(smem + col * MS + UQ * q + UH * hh);
+    };
+    auto chain = [&](auto TWO) __attribute__((always_inline)) {
+        f32x4 An = afrag(0);
+#pragma unroll
+        for (int q = 0; q < (WT_DBG == 1 ? 1 : NQ); q++) {
+            const f32x4 Af = An;
+            if (q + 1 < NQ) An = afrag(q + 1);
+            if constexpr (BF) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Af), __builtin_bit_cast(bf16x8, T.Bf[0][q]), acc0, 0, 0, 0);
+                if constexpr (decltype(TWO)::value)
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Af), __builtin_bit_cast(bf16x8, T.Bf[1][q]), acc1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[e], T.Bf[0][q][e], acc0, 0, 0, 0);
+                    if constexpr (decltype(TWO)::value) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[e], T.Bf[1][q][e], acc1, 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (two) chain(std::true_type{});
+    else chain(std::false_type{});
+    const bool t_of32 = !BF || a.out_f32;
+    auto finish = [&](int cb, const f32x16& acc, float bias2, unsigned(&rw)[16]) __attribute__((always_inline)) {
+        const int n2 = cb * 32 + col;
+        const bool relu2 = cb * 32 < a.relu_cols;  // uniform per block
+        const unsigned off0 = (unsigned)(mb * a.ldc + n2);
+        gfloat* op = (gfloat*)a.out;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float o = acc[r] + bias2;
+            if (a.resid) o = o + __builtin_bit_cast(float, BF ? rw[r] << 16 : rw[r]);
+            if (relu2) o = __builtin_fmaxf(o, 0.f);
+            const unsigned oo = off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * a.ldc);
+            if (n2 < a.Nvalid && (WT_DBG != 2 || a.ldc < 0)) {
+                if (t_of32) put_f32(op + oo, o);
+                else put_bf16((gbf16*)op + oo, o);
+            }
+        }
+    };
+    finish(tw, acc0, bias0, T.rw[0]);
+    if (two) finish(tw + 8, acc1, bias1, T.rw[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The conv kernel.  Streaming: a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
 // chunks as one stream through the LDS ring.  The producers simply keep issuing -- the first chunks of the next
 // tile land while the consumers are still in the previous tile's epilogue -- so the per-tile fixed cost (wave
@@ -271,12 +385,14 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
 // ring has 4 stages in the same 80 KB.  Results differ from the fp32 instruction's in the last bits only (summation order, the dropped
 // terms); the parity gates are the fp32 path's.
 template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false, bool X3 = false>
-__global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
+__global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
     constexpr bool TAIL = FUSE == 1, BONE = FUSE == 2;
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
     static_assert(!X3 || (BM == 64 && (BN * KG == 64) && !BF && !SPAN && PROF < 2), "split-product form: 64x64 and 64x32x2 tiles of fp32 layers");
-    static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1), "the fused forms are built for one 64x64 tile per workgroup");
+    static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1) || (FUSE == 1 && BM == 32 && BN == 128 && KG == 1),
+                  "the fused forms are built for one 64x64 tile per workgroup; the tail GEMM also for one 32x128 tile (tail_wide)");
+    constexpr bool WIDE = BN == 128;
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
@@ -286,7 +402,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : (X3 ? KG * ARB + 3 : KG * ROWS / 32);  // floats per ring stage; LDS-DMA instructions per producer wave per step
     constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x 4 KiB, then WMN*(KG-1) flags
     constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
-    static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64), "four consumer waves, one 32x32 accumulator each");
+    static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64 || BN == 128), "four consumer waves, one 32x32 accumulator each");
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {   // The 280-byte argument block spans five scalar-cache lines and the compiler loads fields where they are first
@@ -534,8 +650,10 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         // of the first two and the weight fragments of the first are requested NOW (older than every LDS-DMA below, so the
         // counted vmcnt waits of the ring are unaffected) and rest in registers this wave does not otherwise need.
         TailRegs<BF> T;
+        WideRegs<BF> TW;
         const int wm2 = wave & 1, g2 = wave >> 1;
-        if constexpr (TAIL) {
+        if constexpr (TAIL && WIDE) wide_load_weights<BF>(a, wave, lane, TW), wide_load_resid<BF>(a, decode(0).m0, wave, lane, TW);  // tail waves 0..3
+        if constexpr (TAIL && !WIDE) {
             const int mb2 = decode(0).m0 + wm2 * 32 + 4 * (lane >> 5);
             tail_load_resid<BF>(a, mb2, 2 + g2, lane, T.rw[0]);
             tail_load_resid<BF>(a, mb2, 4 + g2, lane, T.rw[1]);
@@ -580,7 +698,8 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
         if constexpr (TAIL) {
             __builtin_amdgcn_s_barrier();  // the consumers have put the layer's tile into LDS (one tile per workgroup)
-            tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
+            if constexpr (WIDE) tail_wide<BF>(a, smem, decode(0).m0, wave, lane, TW);
+            else tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
         }
         if constexpr (BONE) {
             const Item it0 = decode(0);
@@ -612,6 +731,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
     };
     Frag F0, F1;
     f32x16 acc;
+    WideRegs<BF> TWc;  // (the wide tail's operands of this consumer wave)
     auto rall = [&](int stg, Frag& F) __attribute__((always_inline)) {
         const float* Ab = smem + stg * STAGE + kg * SUB + (SPAN ? 0 : (wm * 32) * 32);
         const float* Bb = smem + stg * STAGE + kg * SUB + (BM + wn * 32) * 32;
@@ -835,6 +955,7 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
         // here and in the epilogue runs once per tile on a cold instruction cache -- ~35 cycles per instruction
         // measured -- so both are written for instruction count: scalar row bases stepped by additions, one lane offset.)
         float bias = 0.f, sc = 1.f, sh = 0.f;
+        if constexpr (TAIL && WIDE) wide_load_resid<BF>(a, it.m0, 4 + wave, lane, TWc);  // the tail's shortcut values: requested before the K loop
         unsigned rsw[16];  // shortcut values as loaded (fp32 bits, or a zero-extended bf16): converting a bf16 here would make
                            // the compiler wait for the loads BEFORE the K loop (measured: 15 us per 92x92 shortcut layer)
         if (fused && kg == 0) {
@@ -923,8 +1044,9 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
             //     flight behind the current block's epilogue, the producers' shortcut values already in registers.
             // The K order of every output is that of the stand-alone 1x1 layer, and the tile in LDS holds exactly the values
             // that layer would have read back from HBM: results are bit-identical to the unfused plan.
-            constexpr int MS = TAIL_MS<BF>;
+            constexpr int MS = WIDE ? WIDE_MS<BF> : TAIL_MS<BF>;
             const int wm2 = wave & 1, g2 = wave >> 1;  // this wave's share of the tail: row half, column block
+            if constexpr (WIDE) wide_load_weights<BF>(a, 4 + wave, lane, TWc);  // tail waves 4..7: in flight behind the tile's way to LDS and the producers' MFMAs
             {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias));  // the layer's own bias (requested before the K loop)
                 const int k1 = wn * 32 + col;
@@ -938,7 +1060,9 @@ __global__ __launch_bounds__(512, KG == 1 ? 4 : 2) void conv_stream_kernel(const
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            {
+            if constexpr (WIDE) {  // (wm = 0: the tile's 32 rows; the four waves wrote columns 32 wn ..)
+                tail_wide<BF>(a, smem, it.m0, 4 + wave, lane, TWc);
+            } else {
                 TailRegs<BF> T;
                 tail_gemm<BF, 1, false>(a, smem, it.m0, wm2, g2, 0, lane, T);
             }
@@ -1072,7 +1196,7 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     // two workgroups per CU at most (one for the K-group shapes: their ring fills the LDS): more tiles than that are
     // walked by the same workgroups (VNECT_MAXWG: tuning)
     static const int maxwg_env = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 0;
-    const int maxwg = maxwg_env > 0 ? maxwg_env : (KG == 1 ? 512 : 256);
+    const int maxwg = maxwg_env > 0 ? maxwg_env : (KG == 1 && BN <= 64 ? 512 : 256);
     dim3 grid(a.items < maxwg ? a.items : maxwg);
     const size_t lds = stream_lds<BM, BN, KG, NS>();
     // profiling twin: start / end stamps only, or (VNECT_PROF_DETAIL=1, tools/phase_table.py) the per-phase stamps too
@@ -1123,6 +1247,22 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
             const size_t l3 = x3_stream_lds<64, 32, 2, NS>();
             if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>), grid, dim3(512), l3, st, a);
             else hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>), grid, dim3(512), l3, st, a);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (BM == 32 && BN == 128 && KG == 1) {
+        if (a.tail_n > 0) {  // the wide tail (tail_wide): one 32x128 tile per workgroup, K = 128, at most 16 column blocks
+            if (a.x3 || a.bone || a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 128 || a.os != 1 || a.tail_n > 512 || !a.tail_w || !a.tail_bias)
+                return hipErrorInvalidValue;
+#define LAUNCH_WTAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<32, 128, 1, NS, BF, PR, 1>), grid, dim3(512), lds, st, a)
+            if (a.bf16) {
+                if (prof == 0) LAUNCH_WTAIL(true, 0);
+                else LAUNCH_WTAIL(true, 1);
+            } else {
+                if (prof == 0) LAUNCH_WTAIL(false, 0);
+                else LAUNCH_WTAIL(false, 1);
+            }
+#undef LAUNCH_WTAIL
             return hipGetLastError();
         }
     }
@@ -1195,6 +1335,10 @@ static hipError_t setup_stream()
             if (fa.numRegs > 128 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
         }
     }
+    if constexpr (BM == 32 && BN == 128 && KG == 1) {
+        fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 0, 1>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 0, 1>);
+        fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 1, 1>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 1, 1>);
+    }
     if constexpr (BM == 64 && BN == 32 && KG == 2) {
         for (const void* f : {(const void*)conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_stream_lds<64, 32, 2, NS>());
@@ -1212,7 +1356,7 @@ static hipError_t setup_stream()
         // the launch plan assumes two workgroups per CU (one for the K-group shapes): refuse a build that needs more registers
         // or scratch (the per-phase tuning twins, PROF = 2, may spill a few bytes)
         const bool twin = f == (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2> || f == (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>;
-        if (fa.numRegs > (KG == 1 ? 128 : 256) || (fa.localSizeBytes != 0 && !twin)) return hipErrorLaunchOutOfResources;
+        if (fa.numRegs > (KG == 1 && BN <= 64 ? 128 : 256) || (fa.localSizeBytes != 0 && !twin)) return hipErrorLaunchOutOfResources;
     }
     return hipSuccess;
 }
@@ -1225,6 +1369,7 @@ hipError_t conv_setup()
     if ((e = setup_stream<64, 64, 1, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<64, 32, 2, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
+    if ((e = setup_stream<32, 128, 1, 5>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -1239,6 +1384,7 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
     if (KG == 2 && BM == 64 && BN == 32) return launch_stream<64, 32, 2, 5>(a, st);
     if (KG == 4 && BM == 32 && BN == 32) return launch_stream<32, 32, 4, 4>(a, st);
     if (KG == 1 && BM == 64 && BN == 64) return launch_stream<64, 64, 1, 5>(a, st);
+    if (KG == 1 && BM == 32 && BN == 128) return launch_stream<32, 128, 1, 5>(a, st);
     return hipErrorInvalidValue;
 }
 

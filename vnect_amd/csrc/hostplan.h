@@ -284,6 +284,20 @@ inline void pack_tail(const float* Wc, int mid, int cout, std::vector<float>& w2
     for (int k = 0; k < mid; k++)
         for (int n = 0; n < cout; n++) w2[(size_t)n * 64 + k] = Wc[(size_t)k * cout + n];
 }
+// the wide tail's 1x1 weights (1,1,128,cout) in the MFMA's own B-fragment order, so that a wave's load instruction reads one contiguous
+// KiB: [column block of 32][group q][lane = 32 hh + column][e], where the lane's elements of group q are k = UQ q + UH hh + e
+// (fp32: UQ = 8, UH = 4 -- the four 32x32x2 MFMAs of a group; bf16: UQ = 16, UH = 8 -- one 32x32x16 MFMA).  Columns padded to whole
+// blocks with zero weights.
+inline void pack_tail_wide(const float* Wc, int cout, bool bf16, std::vector<float>& w2)
+{
+    const int UQ = bf16 ? 16 : 8, UH = bf16 ? 8 : 4, NQ = 128 / UQ, nb = round_up(cout, 32) / 32;
+    w2.assign((size_t)nb * 32 * 128, 0.f);
+    for (int n = 0; n < cout; n++)
+        for (int k = 0; k < 128; k++) {
+            const int cb = n / 32, col = n % 32, q = k / UQ, hh = (k % UQ) / UH, e = k % UH;
+            w2[((((size_t)cb * NQ + q) * 2 + hh) * 32 + col) * UH + e] = Wc[(size_t)k * cout + n];
+        }
+}
 
 // The two transposed convs (4x4, stride 2, SAME; kernels (kh,kw,Cout,Cin), vnect_model.py:188-196) as 4 sub-pixel phases of ONE
 // launch: out[2i-1+ky, 2j-1+kx, oc] += in[i,j,ic] * W[ky,kx,oc,ic]; phase (py,px) = (oy&1, ox&1):
@@ -361,7 +375,7 @@ inline size_t arena_first_fit(const std::vector<int>& first, const std::vector<i
 struct TileChoice {
     int BM = 64, BN = 64, KG = 1, ks = 1;
 };
-inline bool tile_shape_ok(int BM, int BN, int KG) { return (BM == 64 && BN == 64 && KG == 1) || (BM == 64 && BN == 32 && KG == 2) || (BM == 32 && BN == 32 && KG == 4); }
+inline bool tile_shape_ok(int BM, int BN, int KG) { return (BM == 64 && BN == 64 && KG == 1) || (BM == 64 && BN == 32 && KG == 2) || (BM == 32 && BN == 32 && KG == 4) || (BM == 32 && BN == 128 && KG == 1); }
 inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int nphase, bool bf16, const std::string& name, const char* force,
                               const char* plan)
 {

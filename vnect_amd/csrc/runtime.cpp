@@ -463,13 +463,21 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
 // the 92x92 stage) and has one tile (so the ring is free behind the K loop): ceil(M / 64) <= 512 workgroups.  Results are
 // bit-identical to the two stand-alone launches.  Returns the block output tensor or -1; *fits = false if the shape does not
 // admit the fusion (the caller then builds the two layers).
+//
+// The WIDE form (round 3) does the same for a 3x3 layer with 128 channels -- res3*_branch2b -> res3*_branch2c and the head's
+// res5c_branch2b -> res5c_branch2c (vnect_model.py:62-103,211-217): the 3x3 layer runs on 32 x 128 tiles (as many workgroups as the
+// 64 x 64 plan has tiles, the same MFMA work per wave), a workgroup owns all 128 channels of its 32 pixels, the 1x1 layer (K = 128,
+// up to 512 outputs) is conv.hip's tail_wide.  One workgroup per CU (100-KB ring): ceil(M / 32) <= 256, i.e. up to three scales at
+// 46x46.  Not on a split-product handle (its 3x3 layers keep the 64 x 64 split-product loop).  VNECT_NO_WIDE_TAIL=1: A/B runs.
 int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc, int in, int resid, const std::string& out_name,
-                  int mid, int cout, bool* fits)
+                  int mid, int cout, bool* fits, bool relu2 = true)
 {
     const Tensor tin = h->tensors[in];
     const int EPR = h->bf16 ? 64 : 32;
-    *fits = mid == 64 && cout == 256 && tin.Cs % EPR == 0 && ((long long)tin.S * tin.H * tin.W + 63) / 64 <= 512 &&
-            !h->keep_activations && !getenv("VNECT_NO_TAIL");
+    const long long pixels = (long long)tin.S * tin.H * tin.W;
+    const bool narrow = mid == 64 && cout == 256 && (pixels + 63) / 64 <= 512;
+    const bool wide = mid == 128 && cout <= 512 && (pixels + 31) / 32 <= 256 && !h->x3 && !getenv("VNECT_NO_WIDE_TAIL") && !getenv("VNECT_FORCE_TILE");
+    *fits = (narrow || wide) && tin.Cs % EPR == 0 && !h->keep_activations && !getenv("VNECT_NO_TAIL");
     if (!*fits) return -1;
     const int cin = tin.C;
     const HostArray* Wb = get_w(h, sb + "/weights", {3, 3, cin, mid});
@@ -481,24 +489,27 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     same_pad(tin.H, 3, 1, &ho, &pt), same_pad(tin.W, 3, 1, &wo, &pl);
     Layer L;
     L.op = OP_CONV, L.name = sb + ">" + sc, L.in = in, L.resid = resid;
-    L.out = add_tensor(h, out_name, tin.S, ho, wo, cout, cout);
+    const bool final_maps = sc == "res5c_branch2c";  // feeds the f64 post-processing: stays fp32
+    L.out = add_tensor(h, out_name, tin.S, ho, wo, cout, cout, final_maps);
     ConvArgs& a = L.a;
+    a.out_f32 = final_maps;
     a.S = tin.S, a.H = tin.H, a.W = tin.W, a.Cs = tin.Cs;
     a.Ho = ho, a.Wo = wo, a.M = tin.S * ho * wo, a.stride = 1;
     a.OH = ho, a.OW = wo, a.os = 1, a.nphase = 1;
-    a.ldc = cout, a.ldr = cout, a.relu_cols = cout, a.Nvalid = cout;  // the TAIL's output, shortcut and ReLU
+    a.ldc = cout, a.ldr = cout, a.relu_cols = relu2 ? cout : 0, a.Nvalid = cout;  // the TAIL's output, shortcut and ReLU
     a.bf16 = h->bf16;
     a.ntaps = 9, a.cpt = tin.Cs / EPR, a.K = 9 * tin.Cs;
     for (int ky = 0; ky < 3; ky++)
         for (int kx = 0; kx < 3; kx++) L.dy[ky * 3 + kx] = ky - pt, L.dx[ky * 3 + kx] = kx - pl;
     L.Nreal = mid, L.Kreal = 9 * cin;
     L.flops = 2.0 * a.M * ((double)L.Kreal * mid + (double)mid * cout);
-    L.BM = 64, L.BN = 64, L.KG = 1, a.ksplit = 1;
-    a.Npad = 64;
-    std::vector<float> wp((size_t)64 * a.K, 0.f), bp(64, 0.f), w2, b2(cout, 0.f);
+    L.BM = wide ? 32 : 64, L.BN = mid, L.KG = 1, a.ksplit = 1;
+    a.Npad = mid;
+    std::vector<float> wp((size_t)mid * a.K, 0.f), bp(mid, 0.f), w2, b2(round_up(cout, 32), 0.f);
     plan::pack_conv(Wb->d.data(), 3, cin, mid, tin.Cs, false, h->bf16, a.K, 0, wp);
     for (int n = 0; n < mid; n++) bp[n] = Bb->d[n];
-    plan::pack_tail(Wc->d.data(), mid, cout, w2);
+    if (wide) plan::pack_tail_wide(Wc->d.data(), cout, h->bf16, w2);
+    else plan::pack_tail(Wc->d.data(), mid, cout, w2);
     for (int n = 0; n < cout; n++) b2[n] = Bc->d[n];
     float *dw2 = nullptr, *db2 = nullptr;
     if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
@@ -579,17 +590,24 @@ int finalize_impl(vnect_handle* h)
         h->l_pool1 = (int)h->layers.size() - 1;
     }
     // bottleneck blocks (vnect_model.py:31-165); block output tensors are named resNx
+    // branch2b (3x3) -> branch2c (1x1, + shortcut s, ReLU): one launch where the tail GEMM fits (add_conv_tail), else two
+    auto b_then_c = [&](const std::string& p, int a, int mid, int out, int s) {
+        if (a < 0) return -1;
+        bool fits = false;
+        const int o = add_conv_tail(h, p + "_branch2b", p + "_branch2c", a, s, p, mid, out, &fits);
+        if (fits) return o;
+        const int b = conv(p + "_branch2b", a, 3, 1, mid, true);
+        return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, s, p);
+    };
     auto proj = [&](const std::string& p, int x, int mid, int out, int stride) {
         int s = -1;
         int a = add_conv_pair(h, p + "_branch2a", mid, p + "_branch1", out, x, stride, &s);
-        int b = a < 0 ? -1 : conv(p + "_branch2b", a, 3, 1, mid, true);
-        return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, s, p);
+        return b_then_c(p, a, mid, out, s);
     };
     auto ident = [&](const std::string& p, int x, int mid, int out, int* branch2a = nullptr) {
         int a = conv(p + "_branch2a", x, 1, 1, mid, true);
         if (branch2a) *branch2a = a;
-        int b = a < 0 ? -1 : conv(p + "_branch2b", a, 3, 1, mid, true);
-        return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, x, p);
+        return b_then_c(p, a, mid, out, x);
     };
     // 92x92 stage: each block's 3x3 layer has 64 channels, i.e. one 64-wide tile column, so its 1x1 successor can run as a tail
     // GEMM of the same workgroups (add_conv_tail): 3 launches and 3 x 13 MB of intermediate traffic fewer.  Where the shape does
@@ -724,8 +742,6 @@ int finalize_impl(vnect_handle* h)
         }
     }
     // head (vnect_model.py:211-217)
-    int hd = conv("res5c_branch2b", feat, 3, 1, 128, true);
-    NEED(hd);
     {
         const HostArray* Wk = get_w(h, "res5c_branch2c/kernel", {1, 1, 128, 84});
         if (!Wk) return VNECT_E_ARG;
@@ -734,7 +750,12 @@ int finalize_impl(vnect_handle* h)
         z.d.assign(84, 0.f), z.shape = {84};
         h->weights["res5c_branch2c/weights"] = *Wk;
         h->weights["res5c_branch2c/biases"] = z;
-        h->t_out = conv("res5c_branch2c", hd, 1, 1, 84, false);
+        bool fits = false;
+        h->t_out = add_conv_tail(h, "res5c_branch2b", "res5c_branch2c", feat, -1, "res5c_branch2c", 128, 84, &fits, false);
+        if (!fits) {
+            const int hd = conv("res5c_branch2b", feat, 3, 1, 128, true);
+            h->t_out = hd < 0 ? -1 : conv("res5c_branch2c", hd, 1, 1, 84, false);
+        }
         h->weights.erase("res5c_branch2c/weights"), h->weights.erase("res5c_branch2c/biases");
         NEED(h->t_out);
     }
