@@ -35,7 +35,7 @@ def hp():
     L.hp_extract_2d.argtypes = [f64p, C.c_int, f64p]
     L.hp_squarify.argtypes = [C.c_int, C.c_int, f64p, i32p, i32p, i32p, i32p, i32p, C.c_char_p, C.c_int]
     L.hp_pack_conv.argtypes = [f32p] + [C.c_int] * 9 + [f32p]
-    L.hp_pack_tail.argtypes = [f32p, C.c_int, C.c_int, f32p]
+    L.hp_pack_tail.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
     L.hp_pack_deconv.argtypes = [f32p, f32p, C.c_int, C.c_int, f32p, i32p, i32p]
     L.hp_fold_bn.argtypes = [f32p] * 4 + [C.c_int, C.c_int] + [f32p] * 3
     L.hp_to_bf16.argtypes = [C.c_float]
@@ -180,11 +180,21 @@ def test_conv_weight_packing_round_trip(hp):
     Q = np.zeros((128, 32), np.float32)
     hp.hp_pack_conv(_p(Wb, f32p), 1, 32, 24, 32, 0, 0, 128, 32, 64, _p(Q, f32p))
     assert np.array_equal(P[:64], Wa[0, 0].T) and not P[64:].any() and np.array_equal(Q[64:88], Wb[0, 0].T) and not Q[:64].any()
-    # tail GEMM: (1,1,mid,cout) -> [cout][64]
-    Wt = rng.randn(1, 1, 64, 256).astype(np.float32)
-    T = np.zeros((256, 64), np.float32)
-    hp.hp_pack_tail(_p(Wt, f32p), 64, 256, _p(T, f32p))
-    assert np.array_equal(T, Wt[0, 0].T)
+    # tail GEMMs: (1,1,mid,cout) -> the MFMA's B-fragment order [column block][group q][lane = 32 hh + column][e], element
+    # k = UQ q + UH hh + e of column 32 cb + column (fp32: UQ, UH = 8, 4; bf16: 16, 8); columns padded to whole blocks with zeros
+    for mid, cout, bf16 in ((64, 256, 0), (64, 256, 1), (128, 512, 0), (128, 512, 1), (128, 84, 0), (128, 84, 1)):
+        Wt = rng.randn(1, 1, mid, cout).astype(np.float32)
+        UQ, UH = (16, 8) if bf16 else (8, 4)
+        nb, NQ = (cout + 31) // 32, mid // UQ
+        T = np.full((nb, NQ, 2, 32, UH), np.nan, np.float32)
+        hp.hp_pack_tail(_p(Wt, f32p), mid, cout, bf16, _p(T, f32p))
+        Wp = np.zeros((mid, nb * 32), np.float32)
+        Wp[:, :cout] = Wt[0, 0]
+        for cb in range(nb):
+            for q in range(NQ):
+                for hh in range(2):
+                    k0 = UQ * q + UH * hh
+                    assert np.array_equal(T[cb, q, hh], Wp[k0:k0 + UH, 32 * cb:32 * cb + 32].T), (mid, cout, bf16, cb, q, hh)
 
 
 def test_deconv_phase_layout_matches_the_transposed_conv(hp):

@@ -165,14 +165,12 @@ __device__ __forceinline__ void tail_load_resid(const ConvArgs& a, int mb, int c
 template <bool BF>
 __device__ __forceinline__ void tail_load_b(const ConvArgs& a, int cb, int lane, f32x4 (&Bf)[TailRegs<BF>::NQ])
 {
+    // tail_w is packed in fragment order (hostplan.h: pack_tail): [block][q][lane] x 16 bytes -- one contiguous KiB per instruction
     typedef __attribute__((address_space(1))) const f32x4 cgf4;
-    constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4;  // elements per MFMA group, per lane half
-    const int nrow = cb * 32 + (lane & 31), hh = lane >> 5;
+    constexpr int NQ = TailRegs<BF>::NQ;
+    cgf4* bp = (cgf4*)a.tail_w + cb * (NQ * 64) + lane;
 #pragma unroll
-    for (int q = 0; q < TailRegs<BF>::NQ; q++) {
-        if constexpr (BF) Bf[q] = *(cgf4*)((cgbf16*)a.tail_w + nrow * 64 + UQ * q + UH * hh);
-        else Bf[q] = *(cgf4*)((cgfloat*)a.tail_w + nrow * 64 + UQ * q + UH * hh);
-    }
+    for (int q = 0; q < NQ; q++) Bf[q] = bp[q * 64];
 }
 // NBLK blocks cb0, cb0 + cbs, ...; PRE: T.rw[0], T.rw[1] (blocks 0, 1) and T.Bf (block 0) were requested by the caller
 template <bool BF, int NBLK, bool PRE>
@@ -258,7 +256,7 @@ struct WideRegs {
 template <bool BF>
 __device__ __forceinline__ void wide_load_b(const ConvArgs& a, int cb, int lane, f32x4 (&Bf)[WideRegs<BF>::NQ])
 {
-    // tail_w is packed in fragment order (hostplan.h: pack_tail_wide): [block][q][lane] x 16 bytes -- one contiguous KiB per instruction
+    // tail_w is packed in fragment order (hostplan.h: pack_tail): [block][q][lane] x 16 bytes -- one contiguous KiB per instruction
     typedef __attribute__((address_space(1))) const f32x4 cgf4;
     constexpr int NQ = WideRegs<BF>::NQ;
     cgf4* bp = (cgf4*)a.tail_w + cb * (NQ * 64) + lane;

@@ -277,23 +277,17 @@ inline void pack_conv(const float* W, int k, int cin, int cout, int cp, bool con
                 for (int n = 0; n < cout; n++) wp[(size_t)(n0 + n) * K + kidx] = src[n];
             }
 }
-// tail GEMM's 1x1 weights (1,1,mid,cout) -> [cout][64]
-inline void pack_tail(const float* Wc, int mid, int cout, std::vector<float>& w2)
+// A tail GEMM's 1x1 weights (1,1,mid,cout), mid = 64 (tail_gemm) or 128 (tail_wide), in the MFMA's own B-fragment order, so that a
+// wave's load instruction reads one contiguous KiB (row by row -- [cout][mid], a lane per row -- the same instruction touched 32 cache
+// lines for 32 bytes each, and the wide tail took 16 us instead of 10): [column block of 32][group q][lane = 32 hh + column][e], where
+// the lane's elements of group q are k = UQ q + UH hh + e (fp32: UQ = 8, UH = 4 -- the four 32x32x2 MFMAs of a group; bf16: UQ = 16,
+// UH = 8 -- one 32x32x16 MFMA).  Columns padded to whole blocks with zero weights.
+inline void pack_tail(const float* Wc, int mid, int cout, bool bf16, std::vector<float>& w2)
 {
-    w2.assign((size_t)cout * 64, 0.f);
-    for (int k = 0; k < mid; k++)
-        for (int n = 0; n < cout; n++) w2[(size_t)n * 64 + k] = Wc[(size_t)k * cout + n];
-}
-// the wide tail's 1x1 weights (1,1,128,cout) in the MFMA's own B-fragment order, so that a wave's load instruction reads one contiguous
-// KiB: [column block of 32][group q][lane = 32 hh + column][e], where the lane's elements of group q are k = UQ q + UH hh + e
-// (fp32: UQ = 8, UH = 4 -- the four 32x32x2 MFMAs of a group; bf16: UQ = 16, UH = 8 -- one 32x32x16 MFMA).  Columns padded to whole
-// blocks with zero weights.
-inline void pack_tail_wide(const float* Wc, int cout, bool bf16, std::vector<float>& w2)
-{
-    const int UQ = bf16 ? 16 : 8, UH = bf16 ? 8 : 4, NQ = 128 / UQ, nb = round_up(cout, 32) / 32;
-    w2.assign((size_t)nb * 32 * 128, 0.f);
+    const int UQ = bf16 ? 16 : 8, UH = bf16 ? 8 : 4, NQ = mid / UQ, nb = round_up(cout, 32) / 32;
+    w2.assign((size_t)nb * 32 * mid, 0.f);
     for (int n = 0; n < cout; n++)
-        for (int k = 0; k < 128; k++) {
+        for (int k = 0; k < mid; k++) {
             const int cb = n / 32, col = n % 32, q = k / UQ, hh = (k % UQ) / UH, e = k % UH;
             w2[((((size_t)cb * NQ + q) * 2 + hh) * 32 + col) * UH + e] = Wc[(size_t)k * cout + n];
         }

@@ -184,10 +184,10 @@ void hp_pack_conv(const float* W, int k, int cin, int cout, int cp, int conv1, i
     plan::pack_conv(W, k, cin, cout, cp, conv1 != 0, bf16 != 0, K, n0, v);
     memcpy(wp, v.data(), v.size() * sizeof(float));
 }
-void hp_pack_tail(const float* Wc, int mid, int cout, float* w2)
+void hp_pack_tail(const float* Wc, int mid, int cout, int bf16, float* w2)
 {
     std::vector<float> v;
-    plan::pack_tail(Wc, mid, cout, v);
+    plan::pack_tail(Wc, mid, cout, bf16 != 0, v);
     memcpy(w2, v.data(), v.size() * sizeof(float));
 }
 void hp_pack_deconv(const float* W1, const float* W2, int Npad, int K, float* wp, int* dy16, int* dx16)

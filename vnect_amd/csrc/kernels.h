@@ -54,16 +54,17 @@ struct ConvArgs {
     // with scalar shifts -- no table in the argument block, no dependent scalar load per tap
     unsigned long long dy_pack, dx_pack;
     int tapgrid;  // 1: single tap (0,0); 3: the 3x3 grid with pad 1 (validity masks in closed form); 0: walk the table
-    // Tail GEMM (conv_stream_kernel<..., TAIL = true>; 64x64 tiles, ONE tile per workgroup, N = 64): the layer's own output never
-    // reaches HBM -- relu(acc + bias) stays in LDS as a 64 x 64 tile and feeds a 1x1 conv `tail_w` ([tail_n][64], K contiguous)
-    // whose bias / shortcut / ReLU / output are the fields `tail_bias`, resid, relu_cols, out, ldc, Nvalid above describe.
-    // (res2*_branch2b -> res2*_branch2c, vnect_model.py:38-41,50-53,56-59.)
+    // Tail GEMM (conv_stream_kernel<..., FUSE = 1>; ONE tile per workgroup that holds ALL of the layer's channels: 64x64 tiles for
+    // N = 64, 32x128 tiles for N = 128): the layer's own output never reaches HBM -- relu(acc + bias) stays in LDS as a tile and feeds
+    // a 1x1 conv `tail_w` (K = the layer's N; in MFMA fragment order, hostplan.h: pack_tail) whose bias / shortcut / ReLU / output are
+    // the fields `tail_bias`, resid, relu_cols, out, ldc, Nvalid above describe.  (res2*_branch2b -> res2*_branch2c, res3*_branch2b ->
+    // res3*_branch2c, res5c_branch2b -> res5c_branch2c: vnect_model.py:38-41,50-53,56-59,62-103,211-217.)
     const float* tail_w;
     const float* tail_bias;
     int x3;       // 1: split-product form (VNECT_FP32_SPLIT): `w` holds [Npad][K / 32][3 planes][32] bf16 (hostplan.h: pack_split3), the kernel
                   // splits the fp32 activations three ways in registers and multiplies piece by piece on the bf16 matrix pipe
     int bone;     // 1: FUSE = 2 launch of the transposed conv: the bone-length columns 191 .. 211 (+ zero padding) are written here too
-    int tail_n;   // 0: no tail; else the 1x1 conv's output channels (256: 2 row halves x 8 column blocks over the 8 waves)
+    int tail_n;   // 0: no tail; else the 1x1 conv's output channels (64-wide tile: 256 = 2 row halves x 8 column blocks over the 8 waves; 128-wide: up to 512, tail wave tw takes blocks tw, tw + 8)
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

@@ -508,8 +508,7 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     std::vector<float> wp((size_t)mid * a.K, 0.f), bp(mid, 0.f), w2, b2(round_up(cout, 32), 0.f);
     plan::pack_conv(Wb->d.data(), 3, cin, mid, tin.Cs, false, h->bf16, a.K, 0, wp);
     for (int n = 0; n < mid; n++) bp[n] = Bb->d[n];
-    if (wide) plan::pack_tail_wide(Wc->d.data(), cout, h->bf16, w2);
-    else plan::pack_tail(Wc->d.data(), mid, cout, w2);
+    plan::pack_tail(Wc->d.data(), mid, cout, h->bf16, w2);
     for (int n = 0; n < cout; n++) b2[n] = Bc->d[n];
     float *dw2 = nullptr, *db2 = nullptr;
     if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
