@@ -121,6 +121,47 @@ def test_conv1_span_form_is_bit_identical(weights, oracle_net, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
+    """The launches that carry a second (and third) GEMM behind their K loop -- res2*_branch2b>branch2c on 64x64 tiles, res3*_branch2b>
+    branch2c and the head's res5c_branch2b>res5c_branch2c on 32x128 tiles (conv.hip: tail_gemm, tail_wide), in bf16 with the next
+    block's branch2a chained on (chain_gemm) -- against the same layers as launches of their own (vnect_model.py:38-103,211-217): the
+    final maps must be EQUAL at 3 scales (199 workgroups) and at 4 (the wide form no longer fits one workgroup per CU and the plan
+    falls back by itself) and agree to rounding at 1 and 2 (67 / 133 workgroups; there the stand-alone layers split K), and the launch counts must be what the plan promises.  VNECT_FORCE_CHAIN puts the chain on
+    the fp32 handle too (measured slower there, so off by default -- but it is built, so it is tested)."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    p = n.BF16 if prec == "bf16" else n.FP32
+    for scales in ([1.0], [1.0, 0.7], BASELINE_SCALES, [1, 0.85, 0.7, 0.5]):
+        batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77 + len(scales), smooth=True), scales)
+        outs, counts = {}, {}
+        for tag, env in (("default", {}), ("no_wide", {"VNECT_NO_WIDE_TAIL": "1"}), ("no_tail", {"VNECT_NO_TAIL": "1"}),
+                         ("no_chain", {"VNECT_NO_CHAIN": "1"}), ("force_chain", {"VNECT_FORCE_CHAIN": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            h = _handle(scales, weights, precision=p)
+            for k in env:
+                monkeypatch.delenv(k)
+            outs[tag] = h.forward(batch)
+            counts[tag] = sum(1 for L in h.layers() if ">" in L["name"]), sum(L["name"].count(">") for L in h.layers())
+            h.close()
+        S = len(scales)
+        for tag in outs:
+            if S >= 3:  # the stand-alone layers run whole-K tiles like the fused ones: the same sums in the same order
+                assert np.array_equal(outs[tag], outs["no_tail"]), (scales, tag)
+            else:       # fewer scales: the stand-alone 3x3 layers split K (hostplan.h: choose_tile), so only the order of the sums differs
+                err = float(np.abs(outs[tag] - outs["no_tail"]).max() / np.abs(outs["no_tail"]).max())
+                assert err <= (2e-2 if prec == "bf16" else 1e-5), (scales, tag, err)
+                assert np.array_equal(outs[tag], outs["default"]) or tag in ("no_tail", "no_wide"), (scales, tag)
+        assert counts["no_tail"] == (0, 0)
+        assert counts["no_wide"] == ((3, 3) if S <= 3 else (0, 0))            # the 92x92 tails: up to 512 tiles of 64 rows
+        wide = S <= 3
+        assert counts["no_chain"] == ((8, 8) if wide else (0, 0))
+        assert counts["force_chain"] == ((8, 11) if wide else (0, 0))
+        assert counts["default"] == counts["force_chain" if prec == "bf16" else "no_chain"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_fused_stem_is_bit_identical(weights, monkeypatch, prec):
     """The stem as ONE launch (stem.hip: [gen_input_batch ->] conv1 + ReLU -> max-pool on spatial tiles, vnect_model.py:27-29,
     estimator.py:70-81) against the three stand-alone kernels: pool1 -- read from handles with private buffers, VNECT_FORCE_STEM puts

@@ -247,6 +247,12 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
 #endif
 template <bool BF>
 constexpr int WIDE_MS = BF ? 136 : 132;  // mid row stride in elements: 272 B (bf16) / 528 B (fp32), conflict-free 16-byte reads
+// The chain GEMM's A operand: the tail's OUTPUT tile (32 pixels x 512 channels, what the block writes to HBM) kept in LDS behind the
+// mid tile; row stride 516 / 520 elements (conflict-free 16-byte reads, like the mid tile's)
+template <bool BF>
+constexpr int CHAIN_OS = BF ? 520 : 516;
+template <bool BF>
+constexpr int CHAIN_OFF = 32 * WIDE_MS<BF>;  // elements from the start of the LDS
 template <bool BF>
 struct WideRegs {
     static constexpr int NQ = BF ? 8 : 16;  // MFMA groups over K = 128
@@ -285,7 +291,13 @@ __device__ __forceinline__ void wide_load_weights(const ConvArgs& a, int tw, int
 // wave -- share its matrix pipe: the producer's operands are in registers when the K loop ends, so its MFMAs cover the consumer's
 // wait for its weight fragments.
 template <bool BF>
-__device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, int m0, int tw, int lane, WideRegs<BF>& T)
+constexpr int CHAIN_DEPTH = BF ? 16 : 8;  // weight groups of the chain GEMM in flight ahead of its MFMAs (registers the tail's own weights free)
+// CH: the launch has a chain GEMM behind this tail (chain_gemm below): every block's output also goes to the LDS output tile, and a
+// wave that runs a chain block (cq != nullptr: tail waves 0..3) requests that block's first weight groups BEFORE its stores -- vmcnt
+// counts loads and stores alike on this chip, so loads issued behind the 32 write-through stores could only be waited for together
+// with them.
+template <bool BF, bool CH>
+__device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, int m0, int tw, int lane, WideRegs<BF>& T, f32x4* cq = nullptr)
 {
     constexpr int MS = WIDE_MS<BF>, NQ = WideRegs<BF>::NQ;
     constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4;
@@ -323,6 +335,14 @@ __device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, 
     };
     if (two) chain(std::true_type{});
     else chain(std::false_type{});
+    if constexpr (CH) {
+        if (cq) {
+            typedef __attribute__((address_space(1))) const f32x4 cgf4;
+            cgf4* bp = (cgf4*)a.chain_w + tw * ((512 / (BF ? 16 : 8)) * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < CHAIN_DEPTH<BF>; q++) cq[q] = bp[q * 64];
+        }
+    }
     const bool t_of32 = !BF || a.out_f32;
     auto finish = [&](int cb, const f32x16& acc, float bias2, unsigned(&rw)[16]) __attribute__((always_inline)) {
         const int n2 = cb * 32 + col;
@@ -339,10 +359,64 @@ __device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, 
                 if (t_of32) put_f32(op + oo, o);
                 else put_bf16((gbf16*)op + oo, o);
             }
+            if constexpr (CH) {  // the same value, in the precision it has in HBM, for the chain GEMM
+                const int row = 4 * hh + (r & 3) + 8 * (r >> 2);
+                if constexpr (BF) ((__bf16*)smem)[CHAIN_OFF<BF> + row * CHAIN_OS<BF> + n2] = (__bf16)o;
+                else const_cast<float*>(smem)[CHAIN_OFF<BF> + row * CHAIN_OS<BF> + n2] = o;
+            }
         }
     };
     finish(tw, acc0, bias0, T.rw[0]);
     if (two) finish(tw + 8, acc1, bias1, T.rw[1]);
+}
+
+// The chain GEMM: next block's branch2a (1x1, 512 -> 128, bias, ReLU) on the tile the wide tail has just left in LDS -- a third GEMM
+// in the launch, [32 x 512] x [512 x 128]: four column blocks, one per SIMD, taken by the four PRODUCER waves (tail waves 0..3; each
+// runs its block's whole K = 512 in one accumulator, chunk by chunk like the stand-alone layer: bit-identical).  The weights stream
+// from global memory in fragment order (one KiB per instruction) through a ring of registers, CHAIN_DEPTH groups ahead of the MFMAs
+// (the first of them requested inside tail_wide, in front of its stores).
+template <bool BF>
+__device__ __forceinline__ void chain_gemm(const ConvArgs& a, const float* smem, int m0, int cb, int lane, f32x4 (&Bq)[CHAIN_DEPTH<BF>])
+{
+    typedef __attribute__((address_space(1))) const f32x4 cgf4;
+    constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4, NQ = 512 / UQ, OS = CHAIN_OS<BF>, DEPTH = CHAIN_DEPTH<BF>;
+    const int col = lane & 31, hh = lane >> 5, mb = m0 + 4 * hh;
+    cgf4* bp = (cgf4*)a.chain_w + cb * (NQ * 64) + lane;  // (groups 0 .. DEPTH - 1 were requested by tail_wide)
+    const float bias3 = ((cgfloat*)a.chain_bias)[cb * 32 + col];
+    auto afrag = [&](int q) __attribute__((always_inline)) {
+        if constexpr (BF) return *(const f32x4*)((const __bf16*)smem + CHAIN_OFF<BF> + col * OS + UQ * q + UH * hh);
+        else return *(const f32x4*)(smem + CHAIN_OFF<BF> + col * OS + UQ * q + UH * hh);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    f32x4 An = afrag(0);
+#ifndef CH_DBG
+#define CH_DBG 0  // timing probes of the chain GEMM (wrong results): 1 = the first group's MFMAs only, 2 = no weight loads behind the first DEPTH groups
+#endif
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const f32x4 Af = An, Bf = Bq[q % DEPTH];
+        if (q + 1 < NQ) An = afrag(q + 1);
+        if (CH_DBG == 1 && q > 0) continue;
+        if constexpr (BF) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Af), __builtin_bit_cast(bf16x8, Bf), acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[e], Bf[e], acc, 0, 0, 0);
+        }
+        if (CH_DBG != 2 && q + DEPTH < NQ) Bq[q % DEPTH] = bp[(q + DEPTH) * 64];
+    }
+    const int n3 = cb * 32 + col;
+    const unsigned off0 = (unsigned)(mb * a.chain_ld + n3);
+    gfloat* op = (gfloat*)a.chain_out;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float o = __builtin_fmaxf(acc[r] + bias3, 0.f);
+        const unsigned oo = off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * a.chain_ld);
+        if constexpr (BF) put_bf16((gbf16*)op + oo, o);
+        else put_f32(op + oo, o);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -385,10 +459,10 @@ __device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, 
 template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false, bool X3 = false>
 __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
-    constexpr bool TAIL = FUSE == 1, BONE = FUSE == 2;
+    constexpr bool TAIL = FUSE == 1 || FUSE == 3, BONE = FUSE == 2, CHAIN = FUSE == 3;  // 3: the wide tail with a chain GEMM behind it
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
     static_assert(!X3 || (BM == 64 && (BN * KG == 64) && !BF && !SPAN && PROF < 2), "split-product form: 64x64 and 64x32x2 tiles of fp32 layers");
-    static_assert(FUSE == 0 || (BM == 64 && BN == 64 && KG == 1) || (FUSE == 1 && BM == 32 && BN == 128 && KG == 1),
+    static_assert(FUSE == 0 || (FUSE != 3 && BM == 64 && BN == 64 && KG == 1) || ((FUSE == 1 || FUSE == 3) && BM == 32 && BN == 128 && KG == 1),
                   "the fused forms are built for one 64x64 tile per workgroup; the tail GEMM also for one 32x128 tile (tail_wide)");
     constexpr bool WIDE = BN == 128;
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
@@ -403,13 +477,13 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64 || BN == 128), "four consumer waves, one 32x32 accumulator each");
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    {   // The 280-byte argument block spans five scalar-cache lines and the compiler loads fields where they are first
+    {   // The 344-byte argument block spans six scalar-cache lines and the compiler loads fields where they are first
         // used, one scalar-cache round trip after another (cold: 1.7 us from wave start to the first LDS-DMA): touch every line now
         typedef __attribute__((address_space(4))) const int kint;
         kint* kp = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
-        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64];
-        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4));
-        static_assert(sizeof(ConvArgs) <= 320 && sizeof(ConvArgs) > 256, "touch every 64-byte line of the argument block");
+        const int k0 = kp[0], k1 = kp[16], k2 = kp[32], k3 = kp[48], k4 = kp[64], k5 = kp[80];
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5));
+        static_assert(sizeof(ConvArgs) <= 384 && sizeof(ConvArgs) > 320, "touch every 64-byte line of the argument block");
     }
     // Fields are pinned in SGPRs in three groups -- common, producer-only, consumer-only (the branch is wave-uniform, so
     // each path holds only its own) -- and each group is fetched as a few wide scalar loads with ONE wait.  Left to the
@@ -696,8 +770,16 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         if (pacct) prof[16] = pw, prof[17] = pb, prof[18] = pi;
         if constexpr (TAIL) {
             __builtin_amdgcn_s_barrier();  // the consumers have put the layer's tile into LDS (one tile per workgroup)
-            if constexpr (WIDE) tail_wide<BF>(a, smem, decode(0).m0, wave, lane, TW);
-            else tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
+            if constexpr (WIDE) {
+                f32x4 Cq[CHAIN_DEPTH<BF>];
+                tail_wide<BF, CHAIN>(a, smem, decode(0).m0, wave, lane, TW, Cq);
+                if constexpr (CHAIN) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();  // all eight tail waves have put their blocks of the output tile into LDS
+                    chain_gemm<BF>(a, smem, decode(0).m0, wave, lane, Cq);
+                }
+            } else
+                tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
         }
         if constexpr (BONE) {
             const Item it0 = decode(0);
@@ -1059,7 +1141,11 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                 __builtin_amdgcn_s_barrier();
             }
             if constexpr (WIDE) {  // (wm = 0: the tile's 32 rows; the four waves wrote columns 32 wn ..)
-                tail_wide<BF>(a, smem, it.m0, 4 + wave, lane, TWc);
+                tail_wide<BF, CHAIN>(a, smem, it.m0, 4 + wave, lane, TWc);
+                if constexpr (CHAIN) {  // the chain GEMM belongs to the producer waves; this wave only delivers its blocks
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
             } else {
                 TailRegs<BF> T;
                 tail_gemm<BF, 1, false>(a, smem, it.m0, wm2, g2, 0, lane, T);
@@ -1250,9 +1336,14 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     }
     if constexpr (BM == 32 && BN == 128 && KG == 1) {
         if (a.tail_n > 0) {  // the wide tail (tail_wide): one 32x128 tile per workgroup, K = 128, at most 16 column blocks
-            if (a.x3 || a.bone || a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 128 || a.os != 1 || a.tail_n > 512 || !a.tail_w || !a.tail_bias)
+            if (a.x3 || a.bone || a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 128 || a.os != 1 || a.tail_n > 512 || !a.tail_w || !a.tail_bias ||
+                (a.chain_n != 0 && (a.chain_n != 128 || a.tail_n != 512 || !a.chain_w || !a.chain_bias || !a.chain_out || a.chain_ld < 128)))
                 return hipErrorInvalidValue;
-#define LAUNCH_WTAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<32, 128, 1, NS, BF, PR, 1>), grid, dim3(512), lds, st, a)
+#define LAUNCH_WTAIL(BF, PR)                                                                                                              \
+    do {                                                                                                                                  \
+        if (a.chain_n) hipLaunchKernelGGL((conv_stream_kernel<32, 128, 1, NS, BF, PR, 3>), grid, dim3(512), lds, st, a);                     \
+        else hipLaunchKernelGGL((conv_stream_kernel<32, 128, 1, NS, BF, PR, 1>), grid, dim3(512), lds, st, a);                               \
+    } while (0)
             if (a.bf16) {
                 if (prof == 0) LAUNCH_WTAIL(true, 0);
                 else LAUNCH_WTAIL(true, 1);
@@ -1336,6 +1427,8 @@ static hipError_t setup_stream()
     if constexpr (BM == 32 && BN == 128 && KG == 1) {
         fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 0, 1>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 0, 1>);
         fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 1, 1>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 1, 1>);
+        fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 0, 3>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 0, 3>);
+        fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 1, 3>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 1, 3>);
     }
     if constexpr (BM == 64 && BN == 32 && KG == 2) {
         for (const void* f : {(const void*)conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>}) {

@@ -65,6 +65,14 @@ struct ConvArgs {
                   // splits the fp32 activations three ways in registers and multiplies piece by piece on the bf16 matrix pipe
     int bone;     // 1: FUSE = 2 launch of the transposed conv: the bone-length columns 191 .. 211 (+ zero padding) are written here too
     int tail_n;   // 0: no tail; else the 1x1 conv's output channels (64-wide tile: 256 = 2 row halves x 8 column blocks over the 8 waves; 128-wide: up to 512, tail wave tw takes blocks tw, tw + 8)
+    // Chain GEMM behind the wide tail (conv.hip: chain_gemm): the tail's output tile -- a bottleneck block's output, 32 pixels x 512
+    // channels -- stays in LDS as well and feeds the NEXT block's branch2a (1x1, 512 -> 128, ReLU): `chain_w` (fragment order),
+    // `chain_bias`, output `chain_out` ([M][chain_ld]).  res3*_branch2c -> res3(*+1)_branch2a, vnect_model.py:72-103.
+    const float* chain_w;
+    const float* chain_bias;
+    float* chain_out;
+    int chain_n;  // 0: none; else 128
+    int chain_ld;
 };
 
 struct ReduceArgs {  // split-K second pass: out = epilogue(sum_ks ws[ks])

@@ -43,6 +43,7 @@ struct Layer {
     OpKind op = OP_CONV;
     std::string name;
     int in = -1, resid = -1, out = -1, out2 = -1;
+    int out3 = -1;  // the chain GEMM's output tensor (the next block's branch2a), or -1
     ConvArgs a{};
     ReduceArgs r{};
     int BM = 64, BN = 64, KG = 1;  // tile shape; KG = in-workgroup K groups (conv.hip)
@@ -470,7 +471,7 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
 // up to 512 outputs) is conv.hip's tail_wide.  One workgroup per CU (100-KB ring): ceil(M / 32) <= 256, i.e. up to three scales at
 // 46x46.  Not on a split-product handle (its 3x3 layers keep the 64 x 64 split-product loop).  VNECT_NO_WIDE_TAIL=1: A/B runs.
 int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc, int in, int resid, const std::string& out_name,
-                  int mid, int cout, bool* fits, bool relu2 = true)
+                  int mid, int cout, bool* fits, bool relu2 = true, const std::string& chain_scope = "", int* chain_out = nullptr)
 {
     const Tensor tin = h->tensors[in];
     const int EPR = h->bf16 ? 64 : 32;
@@ -513,6 +514,25 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     float *dw2 = nullptr, *db2 = nullptr;
     if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp) || upload_weights(h, &dw2, w2) || upload(h, &db2, b2)) return -1;
     a.tail_w = dw2, a.tail_bias = db2, a.tail_n = cout;
+    // Chain GEMM (conv.hip: chain_gemm): the NEXT block's branch2a (1x1, 512 -> 128, ReLU) on the output tile while it is still in LDS --
+    // one launch fewer per identity block of the 46x46 stage.  bf16 only: there a launch is mostly fixed cost (+2.9 % frames/s, A/B in
+    // one call); in fp32 the chained layer is MFMA-bound either way (7.6 us of matrix work on the same four SIMDs) and the chain's own
+    // overhead exceeds the launch it saves (-1.5 %).  VNECT_NO_CHAIN=1 / VNECT_FORCE_CHAIN=1: A/B runs and the fp32 form's parity test.
+    if (chain_out) *chain_out = -1;
+    if (wide && cout == 512 && relu2 && !chain_scope.empty() && chain_out && !getenv("VNECT_NO_CHAIN") && (h->bf16 || getenv("VNECT_FORCE_CHAIN"))) {
+        const HostArray* Wn = get_w(h, chain_scope + "/weights", {1, 1, cout, 128});
+        const HostArray* Bn = Wn ? get_w(h, chain_scope + "/biases", {128}) : nullptr;
+        if (!Bn) return -1;
+        std::vector<float> w3, b3(Bn->d.begin(), Bn->d.end());
+        plan::pack_tail(Wn->d.data(), cout, 128, h->bf16, w3);
+        float *dw3 = nullptr, *db3 = nullptr;
+        if (upload_weights(h, &dw3, w3) || upload(h, &db3, b3)) return -1;
+        L.out3 = add_tensor(h, chain_scope, tin.S, ho, wo, 128, 128);
+        a.chain_w = dw3, a.chain_bias = db3, a.chain_n = 128, a.chain_ld = 128;
+        L.name += ">" + chain_scope;
+        L.flops += 2.0 * a.M * (double)cout * 128;
+        *chain_out = L.out3;
+    }
     h->layers.push_back(L);
     return L.out;
 }
@@ -523,6 +543,7 @@ void bind_activations(vnect_handle* h, Layer& L)
     ConvArgs& a = L.a;
     a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
     a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
+    a.chain_out = L.out3 >= 0 ? h->tensors[L.out3].d : nullptr;
     a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
     a.w = L.w, a.bias = L.bias, a.scale = L.scale, a.shift = L.shift, a.ws = h->ws;
     L.r.ws = h->ws, L.r.resid = a.resid, L.r.out = a.out;
@@ -590,23 +611,29 @@ int finalize_impl(vnect_handle* h)
     }
     // bottleneck blocks (vnect_model.py:31-165); block output tensors are named resNx
     // branch2b (3x3) -> branch2c (1x1, + shortcut s, ReLU): one launch where the tail GEMM fits (add_conv_tail), else two
-    auto b_then_c = [&](const std::string& p, int a, int mid, int out, int s) {
+    // (`next`: the identity block behind this one -- where the fused launch takes the wide form, that block's branch2a rides along
+    // as its chain GEMM and `chained` holds its output tensor for ident() to pick up)
+    int chained = -1;
+    std::string chained_for;
+    auto b_then_c = [&](const std::string& p, int a, int mid, int out, int s, const std::string& next = "") {
         if (a < 0) return -1;
         bool fits = false;
-        const int o = add_conv_tail(h, p + "_branch2b", p + "_branch2c", a, s, p, mid, out, &fits);
+        int co = -1;
+        const int o = add_conv_tail(h, p + "_branch2b", p + "_branch2c", a, s, p, mid, out, &fits, true, next.empty() ? "" : next + "_branch2a", &co);
+        if (fits && co >= 0) chained = co, chained_for = next;
         if (fits) return o;
         const int b = conv(p + "_branch2b", a, 3, 1, mid, true);
         return b < 0 ? -1 : conv(p + "_branch2c", b, 1, 1, out, true, s, p);
     };
-    auto proj = [&](const std::string& p, int x, int mid, int out, int stride) {
+    auto proj = [&](const std::string& p, int x, int mid, int out, int stride, const std::string& next = "") {
         int s = -1;
         int a = add_conv_pair(h, p + "_branch2a", mid, p + "_branch1", out, x, stride, &s);
-        return b_then_c(p, a, mid, out, s);
+        return b_then_c(p, a, mid, out, s, next);
     };
-    auto ident = [&](const std::string& p, int x, int mid, int out, int* branch2a = nullptr) {
-        int a = conv(p + "_branch2a", x, 1, 1, mid, true);
-        if (branch2a) *branch2a = a;
-        return b_then_c(p, a, mid, out, x);
+    auto ident = [&](const std::string& p, int x, int mid, int out, const std::string& next = "") {
+        int a = chained_for == p ? chained : conv(p + "_branch2a", x, 1, 1, mid, true);
+        chained_for.clear();
+        return b_then_c(p, a, mid, out, x, next);
     };
     // 92x92 stage: each block's 3x3 layer has 64 channels, i.e. one 64-wide tile column, so its 1x1 successor can run as a tail
     // GEMM of the same workgroups (add_conv_tail): 3 launches and 3 x 13 MB of intermediate traffic fewer.  Where the shape does
@@ -663,11 +690,14 @@ int finalize_impl(vnect_handle* h)
             NEED(r);
         }
     }
-    r = proj("res3a", r, 128, 512, 2);
+    r = proj("res3a", r, 128, 512, 2, "res3b");
     NEED(r);
-    for (const char* p : {"res3b", "res3c", "res3d"}) {
-        r = ident(p, r, 128, 512);
-        NEED(r);
+    {
+        const char* blocks[] = {"res3b", "res3c", "res3d", ""};
+        for (int i = 0; i < 3; i++) {
+            r = ident(blocks[i], r, 128, 512, blocks[i + 1]);
+            NEED(r);
+        }
     }
     r = proj("res4a", r, 256, 1024, 2);
     NEED(r);
@@ -777,7 +807,7 @@ int finalize_impl(vnect_handle* h)
         touch(h->t_input4, -1);  // written by the pre-processing
         for (int l = 0; l < nl; l++) {
             const Layer& L = h->layers[l];
-            touch(L.in, l), touch(L.resid, l), touch(L.out, l), touch(L.out2, l);
+            touch(L.in, l), touch(L.resid, l), touch(L.out, l), touch(L.out2, l), touch(L.out3, l);
         }
         touch(h->t_out, nl);  // read by the post-processing
         std::vector<size_t> need(nt), off;
