@@ -124,28 +124,37 @@ def test_conv1_span_form_is_bit_identical(weights, oracle_net, monkeypatch):
 def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
     """The launches that carry a second (and third) GEMM behind their K loop -- res2*_branch2b>branch2c on 64x64 tiles, res3*_branch2b>
     branch2c and the head's res5c_branch2b>res5c_branch2c on 32x128 tiles (conv.hip: tail_gemm, tail_wide), in bf16 with the next
-    block's branch2a chained on (chain_gemm) -- against the same layers as launches of their own (vnect_model.py:38-103,211-217): the
-    final maps must be EQUAL at 3 scales (199 workgroups) and at 4 (the wide form no longer fits one workgroup per CU and the plan
-    falls back by itself) and agree to rounding at 1 and 2 (67 / 133 workgroups; there the stand-alone layers split K), and the launch counts must be what the plan promises.  VNECT_FORCE_CHAIN puts the chain on
-    the fp32 handle too (measured slower there, so off by default -- but it is built, so it is tested)."""
+    block's branch2a chained on (chain_gemm) --, and the stem launch that also runs res2a_branch2a + res2a_branch1 on its pooled tile
+    (stem.hip, PAIR) -- against the same layers as launches of their own (vnect_model.py:32-103,211-217): the final maps must be EQUAL
+    at 3 scales (199 workgroups) and at 4 (the wide form no longer fits one workgroup per CU and the plan falls back by itself) and
+    agree to rounding at 1 and 2 (67 / 133 workgroups; there the stand-alone layers split K), and the launch counts must be what the
+    plan promises.  VNECT_FORCE_CHAIN puts the chain on the fp32 handle too (measured slower there, so off by default -- but it is
+    built, so it is tested)."""
     import oracle
     from tests import helpers
     n = _native()
     p = n.BF16 if prec == "bf16" else n.FP32
     for scales in ([1.0], [1.0, 0.7], BASELINE_SCALES, [1, 0.85, 0.7, 0.5]):
         batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77 + len(scales), smooth=True), scales)
-        outs, counts = {}, {}
+        outs, counts, joints = {}, {}, {}
+        frame = helpers.synth_frame(91 + len(scales), 368, 300, smooth=True)
         for tag, env in (("default", {}), ("no_wide", {"VNECT_NO_WIDE_TAIL": "1"}), ("no_tail", {"VNECT_NO_TAIL": "1"}),
-                         ("no_chain", {"VNECT_NO_CHAIN": "1"}), ("force_chain", {"VNECT_FORCE_CHAIN": "1"})):
+                         ("no_chain", {"VNECT_NO_CHAIN": "1"}), ("force_chain", {"VNECT_FORCE_CHAIN": "1"}),
+                         ("no_stem_pair", {"VNECT_NO_STEM_PAIR": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             h = _handle(scales, weights, precision=p)
             for k in env:
                 monkeypatch.delenv(k)
             outs[tag] = h.forward(batch)
+            if tag in ("default", "no_stem_pair"):  # the stem's pair GEMM from the frame as well (forward() feeds it the batch tensor)
+                j2, j3 = h.infer(frame, T0 + 5, T0 + 5.001)
+                joints[tag] = (j2, j3, h.activation("res5c_branch2c"))
             counts[tag] = sum(1 for L in h.layers() if ">" in L["name"]), sum(L["name"].count(">") for L in h.layers())
             h.close()
         S = len(scales)
+        for x, y in zip(joints["default"], joints["no_stem_pair"]):
+            assert np.array_equal(x, y), scales
         for tag in outs:
             if S >= 3:  # the stand-alone layers run whole-K tiles like the fused ones: the same sums in the same order
                 assert np.array_equal(outs[tag], outs["no_tail"]), (scales, tag)
@@ -158,7 +167,7 @@ def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
         wide = S <= 3
         assert counts["no_chain"] == ((8, 8) if wide else (0, 0))
         assert counts["force_chain"] == ((8, 11) if wide else (0, 0))
-        assert counts["default"] == counts["force_chain" if prec == "bf16" else "no_chain"]
+        assert counts["default"] == counts["no_stem_pair"] == counts["force_chain" if prec == "bf16" else "no_chain"]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

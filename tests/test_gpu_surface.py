@@ -399,7 +399,7 @@ def test_bench_line_contract():
     assert "configs[1]" in d["config"]["workload"] and d["config"]["h2d_in_timed_region"] is False
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0.2 < rf["frac"] < 1.0 and rf["launches_per_frame"] == 40 and "traffic" in rf
+    assert 0.2 < rf["frac"] < 1.0 and 30 <= rf["launches_per_frame"] <= 45 and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["bf16"]["dtype"] == "bf16" and d["bf16"]["value"] > d["value"] and d["bf16"]["roofline"]["bound"] == "hbm"

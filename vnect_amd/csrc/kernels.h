@@ -138,6 +138,13 @@ struct StemArgs {
     const float* w;        // conv1's packed weights as the stand-alone layer has them: fp32 [64][7 rows][8 px][4 ch], bf16 [64][4 row pairs][2][8][4]
     const float* bias;     // [64]
     void* out;             // pool1 (S,92,92,64), fp32 / bf16
+    // PAIR form (round 3): res2a_branch2a (1x1, 64 -> 64, ReLU) + res2a_branch1 (1x1, 64 -> 256), vnect_model.py:32-35, on the pooled
+    // tile while it is in LDS -- pool1 is then never written: weights of both layers side by side in MFMA fragment order
+    // (hostplan.h: pack_tail over the concatenated [64][320]), biases [320], the two output tensors (S,92,92,64) / (S,92,92,256)
+    const float* pair_w;   // nullptr: no pair
+    const float* pair_bias;
+    void* pair_out_a;
+    void* pair_out_b;
     unsigned long long* prof;      // profiling twin: start stamp (workgroup 0) ...
     unsigned long long* prof_end;  // ... and every workgroup's end stamp, like ConvArgs
     int S, groups;         // images; row groups per image (grid = S * groups * 4 tiles)

@@ -49,6 +49,7 @@ struct Layer {
     int BM = 64, BN = 64, KG = 1;  // tile shape; KG = in-workgroup K groups (conv.hip)
     int dy[MAX_TAPS] = {}, dx[MAX_TAPS] = {};  // filter taps [phase*ntaps + tap] (host side; the kernel gets them packed)
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    float* frag_w = nullptr;  // a 1x1 pair on 64 input channels: the same weights in MFMA fragment order, for the stem's PAIR form
     int Nreal = 0, Kreal = 0;
     double flops = 0;
     float last_ms = 0;
@@ -76,6 +77,7 @@ struct vnect_handle {
     // The stem as one launch (stem.hip): conv1 + pool1 [+ gen_input_batch].  0: off (the stand-alone layers), 1: from the batch
     // tensor (behind pyramid_kernel; also what vnect_forward uses), 2: from the frame (no pyramid launch, no batch tensor).
     int stem_mode = 0;
+    bool stem_pair = false;  // the stem launch also runs res2a_branch2a + res2a_branch1 (stem.hip, PAIR): layer l_pool1 + 1 is skipped
     bool stem_frame_ok = false;  // every tile's rectangle of frame bytes fits the kernel's LDS scratch at the current scales
     ScaleTabs stabs_host{};      // the host's copy of d_stabs (plan::stem_frame_fits reads it)
     int l_conv1 = -1, l_pool1 = -1;  // the two layers a stem launch stands for
@@ -453,6 +455,17 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
     for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
     if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp)) return -1;
+    if (k == 1 && stride == 1 && cin == 64 && tin.Cs == 64 && cout_a == 64 && cout_b == 256) {
+        // res2a_branch2a + res2a_branch1 read pool1: the stem can run them on its pooled tile (setup_stem) and wants the weights in
+        // fragment order, both layers side by side ([k][n] with n over the 64 + 256 outputs)
+        std::vector<float> cat((size_t)64 * 320), fw;
+        for (int kk = 0; kk < 64; kk++) {
+            for (int n = 0; n < 64; n++) cat[(size_t)kk * 320 + n] = Wa->d[(size_t)kk * 64 + n];
+            for (int n = 0; n < 256; n++) cat[(size_t)kk * 320 + 64 + n] = Wb->d[(size_t)kk * 256 + n];
+        }
+        plan::pack_tail(cat.data(), 64, 320, h->bf16, fw);
+        if (upload_weights(h, &L.frag_w, fw)) return -1;
+    }
     h->layers.push_back(L);
     *second = L.out2;
     return L.out;
@@ -555,7 +568,7 @@ void bind_activations(vnect_handle* h, Layer& L)
 // three launches, VNECT_STEM=batch keeps pyramid_kernel and fuses conv1 + pool1 only (A/B runs).
 void setup_stem(vnect_handle* h)
 {
-    h->stem_mode = 0;
+    h->stem_mode = 0, h->stem_pair = false;
     if (h->l_conv1 < 0 || h->l_pool1 != h->l_conv1 + 1) return;
     const Layer& C = h->layers[h->l_conv1];
     const Tensor& tin = h->tensors[h->t_input4];
@@ -576,6 +589,19 @@ void setup_stem(vnect_handle* h)
     a.groups = plan::stem_groups(a.S, a.row0);
     // (a lane's tables are lane 0's: build_twin copies stabs_host before calling this)
     h->stem_frame_ok = h->stem_mode == 2 && plan::stem_frame_fits(h->stabs_host, a.S, a.scale_base, a.groups, a.row0, h->bf16);
+    // PAIR form: the launch behind pool1 is res2a_branch2a + res2a_branch1 (1x1 on pool1's 64 channels) and nothing else reads pool1:
+    // the stem runs it on the pooled tile and pool1 is never written.  Not with per-layer read-back (pool1 must exist there).
+    // VNECT_NO_STEM_PAIR=1: A/B runs.
+    h->stem_pair = false;
+    const size_t lp = (size_t)h->l_pool1 + 1;
+    if (!h->keep_activations && !getenv("VNECT_NO_STEM_PAIR") && lp < h->layers.size()) {
+        const Layer& P = h->layers[lp];
+        if (P.op == OP_CONV && P.frag_w && P.in == h->layers[h->l_pool1].out && P.out >= 0 && P.out2 >= 0 && P.a.Npad == 320 &&
+            P.a.split_n == 64 && P.a.relu_cols == 64 && P.a.ldc == 64 && P.a.ldc2 == 256 && P.a.M == a.S * 92 * 92) {
+            a.pair_w = P.frag_w, a.pair_bias = P.bias, a.pair_out_a = h->tensors[P.out].d, a.pair_out_b = h->tensors[P.out2].d;
+            h->stem_pair = true;
+        }
+    }
 }
 
 int finalize_impl(vnect_handle* h)
@@ -808,6 +834,9 @@ int finalize_impl(vnect_handle* h)
         for (int l = 0; l < nl; l++) {
             const Layer& L = h->layers[l];
             touch(L.in, l), touch(L.resid, l), touch(L.out, l), touch(L.out2, l), touch(L.out3, l);
+            // the stem may run this pair itself (setup_stem, PAIR form) and then writes its outputs while it still reads the batch tensor:
+            // they must not share addresses with anything alive from conv1 on
+            if (L.frag_w && l == h->l_pool1 + 1) touch(L.out, h->l_conv1), touch(L.out2, h->l_conv1);
         }
         touch(h->t_out, nl);  // read by the post-processing
         std::vector<size_t> need(nt), off;
@@ -879,6 +908,7 @@ int finalize_impl(vnect_handle* h)
         h->conv_launches += 1;
     }
     setup_stem(h);
+    if (h->stem_pair) h->conv_launches -= 1;
     return VNECT_OK;
 }
 
@@ -898,6 +928,7 @@ int run_network(vnect_handle* h, bool timed, bool stem_done = false)
             }
             continue;
         }
+        if (h->stem_mode && h->stem_pair && li == h->l_pool1 + 1) continue;  // ran inside the stem launch
         if (L.op == OP_CONV) {
             ConvArgs a = L.a;
             a.prof = timed ? h->d_prof + PROF_SLOTS * (&L - h->layers.data()) : nullptr;
@@ -1341,7 +1372,7 @@ int collect_impl(vnect_handle* h, double* j2, float* j3, int32_t* stream_out = n
             return e;
         };
         auto direct = [&](size_t a, size_t b) {  // no kernel in between (the stem stands for conv1 AND pool1)
-            return (b == a + 1 || (h->stem_mode && (int)a == h->l_conv1 && b == a + 2)) && h->layers[a].a.ksplit == 1;
+            return (b == a + 1 || (h->stem_mode && (int)a == h->l_conv1 && b == a + (h->stem_pair ? 3 : 2))) && h->layers[a].a.ksplit == 1;
         };
         for (size_t c = 0; c + 1 < convs.size(); c++)
             if (direct(convs[c], convs[c + 1]) && t_start(convs[c + 1]) > t_end(convs[c]))

@@ -21,7 +21,10 @@
 //      into the up to four pooling windows that contain it with ds_max_f32 on a 29 KB pooled tile (zero-initialised: ReLU outputs are
 //      >= 0; max is exact and order-free, so this is bit-identical to maxpool_kernel; TF's SAME pool pads 0 before / 1 after for
 //      184 -> 92 and padding never wins);
-//   4. writes the pooled tile with 16-byte write-through stores.
+//   4. writes the pooled tile with 16-byte write-through stores -- or (PAIR, round 3) does not write it at all: the two 1x1 layers that
+//      read pool1, res2a_branch2a (64 -> 64, ReLU) and res2a_branch1 (64 -> 256) (vnect_model.py:32-35; one launch of their own so far),
+//      run here as a second GEMM on the pooled tile in LDS -- [92 or 115 pixels] x [64] x [64 x 320], K in the stand-alone launch's
+//      order, so bit-identical to it -- and their outputs are what the launch stores.  One launch and pool1's round trip fewer.
 #include "kernels.h"
 #include "pyramid.h"
 
@@ -60,12 +63,21 @@ static_assert(STEM_SCR_REG % 16 == 0 && STEM_PH <= 32 && STEM_PW <= 104, "scratc
 template <bool BF, bool FRAME = false>
 constexpr size_t stem_lds()
 {
-    return (size_t)STEM_PH * STEM_PW * 4 * (BF ? 2 : 4) + (size_t)STEM_MAXH * STEM_TW * 64 * 4 + (FRAME ? STEM_SCR_BYTES : 0);
+    // patch, pooled tile, (FRAME) scratch, and 512 bytes for the PAIR form's table of output-pixel offsets
+    return (size_t)STEM_PH * STEM_PW * 4 * (BF ? 2 : 4) + (size_t)STEM_MAXH * STEM_TW * 64 * 4 + (FRAME ? STEM_SCR_BYTES : 0) + 512;
 }
 
 // FRAME: the patch is computed from the uint8 frame instead of being copied from the batch tensor (the host takes this form only for
 // frames whose squarify step is a copy, and only if every tile's rectangle fits the scratch: plan::stem_frame_fits)
-template <bool BF, bool FRAME, bool PROF>
+// scalar write-through stores (conv.hip's epilogue stores: the bytes leave the L2 while the kernel runs)
+__device__ __forceinline__ void stem_put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stem_put(__bf16* p, float v)
+{
+    const __bf16 b = (__bf16)v;  // round to nearest even
+    __hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool BF, bool FRAME, bool PROF, bool PAIR = false>
 __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 {
     typedef typename std::conditional<BF, __bf16, float>::type T;
@@ -112,6 +124,18 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
         }
     }
     const float bias = a.bias[nrowB];
+
+    // PAIR: element offset (into the 64-channel output tensor) of the pixel behind each of the tile's up to 128 GEMM rows, one entry
+    // per thread now instead of 16 divisions per lane later.  Rows past the tile point at the tensors' slack pixels (64 behind the
+    // last real one, runtime.cpp: never read), so that the stores need no per-row branch.
+    unsigned* const pixtab = (unsigned*)((char*)smem + stem_lds<BF, FRAME>() - 512);
+    if constexpr (PAIR) {
+        if (tid < 128) {
+            const int py = tid / STEM_TW, px = tid - py * STEM_TW;
+            const int pixel = tid < h * STEM_TW ? ((sI * 92 + r0 + py) * 92 + STEM_TW * c + px) : a.S * 92 * 92 + (tid & 31);
+            pixtab[tid] = (unsigned)pixel * 64u;
+        }
+    }
 
     // ---- 1. the input patch --------------------------------------------------------------------------------------------
     for (int i = tid; i < h * STEM_TW * 16; i += STEM_THREADS) ((f32x4*)pooled)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -336,6 +360,77 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
     }
     __syncthreads();
 
+    if constexpr (PAIR) {
+        // ---- 4'. the pair GEMM: rows = the tile's pooled pixels (row-major, 32 per block: 3 or 4 blocks), columns = 64 + 256 channels
+        // (10 blocks), K = 64.  Wave (rb = wave & 3, half = wave >> 2) takes row block rb and column blocks 5 half .. 5 half + 4: its A
+        // fragments (read once; the tile's rows are 256 B apart, so these reads conflict -- 8 of them per wave) serve all five.
+        typedef __attribute__((address_space(1))) const f32x4 cgf4;
+        constexpr int NQ = BF ? 4 : 8;
+        const int npx = h * STEM_TW, rb = wave & 3, cb0 = 5 * (wave >> 2);
+        if (rb * 32 < npx) {  // (uniform)
+            int ia = rb * 32 + col;
+            if (ia >= npx) ia = 0;  // rows past the tile read pixel 0: finite values, results unused
+            f32x4 Af[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                if constexpr (BF) {  // the pooled values are bf16 numbers held as fp32 (rounded before the max): the conversion is exact
+                    const f32x4 lo = *(const f32x4*)(pooled + ia * 64 + 16 * q + 8 * hh), hi = *(const f32x4*)(pooled + ia * 64 + 16 * q + 8 * hh + 4);
+                    const bf16x8 v = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+                    Af[q] = __builtin_bit_cast(f32x4, v);
+                } else
+                    Af[q] = *(const f32x4*)(pooled + ia * 64 + 8 * q + 4 * hh);
+            }
+            // output pixel offsets of the lane's 16 C/D rows (row = (r & 3) + 8 (r >> 2) + 4 hh): four 16-byte reads of the table
+            unsigned offa[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t4 = *(const u32x4*)(pixtab + rb * 32 + 4 * hh + 8 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) offa[4 * g4 + e] = t4[e];
+            }
+            cgf4* bp = (cgf4*)a.pair_w + lane;
+            f32x4 Bc[NQ], Bn[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) Bc[q] = bp[(cb0 * NQ + q) * 64], Bn[q] = Bc[q];
+            // A LOOP, not five unrolled copies: this code runs once per wave on a cold instruction cache (~35 cycles per instruction
+            // fetched, conv.hip), and the first version -- 1 500 straight-line instructions with a branch around every store -- made the
+            // launch 23 us longer than the stand-alone pair launch it replaced.
+#pragma unroll 1
+            for (int b = 0; b < 5; b++) {
+                const int cb = cb0 + b, n2 = cb * 32 + col;
+                if (b + 1 < 5) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) Bn[q] = bp[((cb + 1) * NQ + q) * 64];
+                }
+                const float bias2 = a.pair_bias[n2];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    if constexpr (BF) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Af[q]), __builtin_bit_cast(bf16x8, Bc[q]), acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[q][e], Bc[q][e], acc, 0, 0, 0);
+                    }
+                }
+                // columns 0..63 = res2a_branch2a (ReLU), 64..319 = res2a_branch1 (none): uniform per block
+                const bool first = cb < 2;
+                T* ob = first ? (T*)a.pair_out_a + n2 : (T*)a.pair_out_b + (n2 - 64);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = acc[r] + bias2;
+                    stem_put(ob + (first ? offa[r] : offa[r] * 4u), first ? __builtin_fmaxf(v, 0.f) : v);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; q++) Bc[q] = Bn[q];
+            }
+        }
+        if (PROF && tid == 0 && blockIdx.x < PROF_WGS) a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        return;
+    }
     // ---- 4. the pooled tile: rows r0 .. r1 - 1, columns 23 c .. 23 c + 22 of image sI, 64 channels (16 units of 4) ---------------
     for (int i = tid; i < h * STEM_TW * 16; i += STEM_THREADS) {
         const int cell = i >> 4, u = i & 15;
@@ -352,6 +447,9 @@ hipError_t stem_setup()
     hipError_t e;
 #define STEM_ATTR(BF, FR, PR)                                                                                                        \
     if ((e = hipFuncSetAttribute((const void*)stem_kernel<BF, FR, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_lds<BF, FR>())) != \
+        hipSuccess)                                                                                                                  \
+        return e;                                                                                                                    \
+    if ((e = hipFuncSetAttribute((const void*)stem_kernel<BF, FR, PR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_lds<BF, FR>())) != \
         hipSuccess)                                                                                                                  \
         return e;
     STEM_ATTR(false, false, false) STEM_ATTR(false, false, true) STEM_ATTR(false, true, false) STEM_ATTR(false, true, true)
@@ -372,9 +470,14 @@ hipError_t launch_stem(const StemArgs& a_in, hipStream_t st)
         if (hgt < 1 || hgt > STEM_MAXH) return hipErrorInvalidValue;
     }
     if (!a.w || !a.bias || !a.out || (a.from_frame ? (!a.fp || !a.tabs || !a.dyn.frame) : !a.batch)) return hipErrorInvalidValue;
+    if (a.pair_w && (!a.pair_bias || !a.pair_out_a || !a.pair_out_b)) return hipErrorInvalidValue;
     const dim3 grid(a.S * a.groups * 4), block(STEM_THREADS);
     const bool prof = a.prof != nullptr;
-#define STEM_GO(BF, FR, PR) hipLaunchKernelGGL((stem_kernel<BF, FR, PR>), grid, block, (stem_lds<BF, FR>()), st, a)
+#define STEM_GO(BF, FR, PR)                                                                                              \
+    do {                                                                                                                 \
+        if (a.pair_w) hipLaunchKernelGGL((stem_kernel<BF, FR, PR, true>), grid, block, (stem_lds<BF, FR>()), st, a);       \
+        else hipLaunchKernelGGL((stem_kernel<BF, FR, PR>), grid, block, (stem_lds<BF, FR>()), st, a);                    \
+    } while (0)
     if (a.bf16) {
         if (a.from_frame) { if (prof) STEM_GO(true, true, true); else STEM_GO(true, true, false); }
         else { if (prof) STEM_GO(true, false, true); else STEM_GO(true, false, false); }
