@@ -173,9 +173,15 @@ __device__ __forceinline__ void tail_load_b(const ConvArgs& a, int cb, int lane,
     for (int q = 0; q < NQ; q++) Bf[q] = bp[q * 64];
 }
 // NBLK blocks cb0, cb0 + cbs, ...; PRE: T.rw[0], T.rw[1] (blocks 0, 1) and T.Bf (block 0) were requested by the caller
-template <bool BF, int NBLK, bool PRE>
+// The 64-wide tail's chain (bf16 only, FUSE = 3 on 64x64 tiles): like the wide tail's, the block output tile (64 pixels x 256 channels)
+// is kept in LDS behind the mid tile -- row stride 264 elements -- and the NEXT block's branch2a (1x1, 256 -> 64, ReLU:
+// res2a -> res2b_branch2a, vnect_model.py:44-47) runs on it as a third GEMM (chain_narrow).
+constexpr int NCHAIN_OS = 264;
+constexpr int NCHAIN_OFF = 64 * TAIL_MS<true>;  // bf16 elements from the start of the LDS
+template <bool BF, int NBLK, bool PRE, bool CH = false>
 __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, int m0, int wm, int cb0, int cbs, int lane, TailRegs<BF>& T)
 {
+    static_assert(!CH || BF, "the 64-wide chain exists in bf16 only");
     constexpr int MS = TAIL_MS<BF>, NQ = TailRegs<BF>::NQ;
     constexpr int UQ = BF ? 16 : 8, UH = BF ? 8 : 4;
     const int col = lane & 31, hh = lane >> 5;
@@ -226,6 +232,8 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
                     const float o = __builtin_fmaxf(acc[r] + bias2 + __builtin_bit_cast(float, rw[r] << 16), 0.f);
                     put_bf16(ob + off0, o);
                     ob += ((r & 3) == 3 ? 5 : 1) * a.ldc;
+                    if constexpr (CH)  // (the host chains only behind this case: shortcut + ReLU, bf16 output, all 256 columns valid)
+                        ((__bf16*)smem)[NCHAIN_OFF + (wm * 32 + 4 * hh + (r & 3) + 8 * (r >> 2)) * NCHAIN_OS + n2] = (__bf16)o;
                 }
             }
         } else {
@@ -475,6 +483,35 @@ __device__ __forceinline__ void chain_gemm(const ConvArgs& a, const float* smem,
     }
 }
 
+// [64 x 256] x [256 x 64]: 2 row halves x 2 column blocks, one per producer wave (rh = wave & 1, cb = wave >> 1), K = 256 in one
+// accumulator (16 MFMAs: the stand-alone layer's order), weights in fragment order from L2.
+__device__ __forceinline__ void chain_narrow(const ConvArgs& a, const float* smem, int m0, int wave, int lane)
+{
+    typedef __attribute__((address_space(1))) const f32x4 cgf4;
+    const int rh = wave & 1, cb = wave >> 1, col = lane & 31, hh = lane >> 5;
+    cgf4* bp = (cgf4*)a.chain_w + cb * (16 * 64) + lane;
+    f32x4 Bq[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) Bq[q] = bp[q * 64];
+    const float bias3 = ((cgfloat*)a.chain_bias)[cb * 32 + col];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all eight tail waves have put their blocks of the output tile into LDS
+    const __bf16* at = (const __bf16*)smem + NCHAIN_OFF + (rh * 32 + col) * NCHAIN_OS + 8 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const f32x4*)(at + 16 * q)), __builtin_bit_cast(bf16x8, Bq[q]), acc, 0, 0, 0);
+    const unsigned off0 = (unsigned)((m0 + rh * 32 + 4 * hh) * a.chain_ld + cb * 32 + col);
+    gbf16* op = (gbf16*)a.chain_out;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        put_bf16(op + off0, __builtin_fmaxf(acc[r] + bias3, 0.f));
+        op += ((r & 3) == 3 ? 5 : 1) * a.chain_ld;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The conv kernel.  Streaming: a workgroup walks SEVERAL work items (output tile x K slice) and treats their K
 // chunks as one stream through the LDS ring.  The producers simply keep issuing -- the first chunks of the next
@@ -518,7 +555,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     constexpr bool TAIL = FUSE == 1 || FUSE == 3, BONE = FUSE == 2, CHAIN = FUSE == 3;  // 3: the wide tail with a chain GEMM behind it
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
     static_assert(!X3 || (BM == 64 && (BN * KG == 64) && !BF && !SPAN && PROF < 2), "split-product form: 64x64 and 64x32x2 tiles of fp32 layers");
-    static_assert(FUSE == 0 || (FUSE != 3 && BM == 64 && BN == 64 && KG == 1) || ((FUSE == 1 || FUSE == 3) && BM == 32 && BN == 128 && KG == 1),
+    static_assert(FUSE == 0 || ((FUSE != 3 || (BF && !X3)) && BM == 64 && BN == 64 && KG == 1) || ((FUSE == 1 || FUSE == 3) && BM == 32 && BN == 128 && KG == 1),
                   "the fused forms are built for one 64x64 tile per workgroup; the tail GEMM also for one 32x128 tile (tail_wide)");
     constexpr bool WIDE = BN == 128;
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
@@ -834,8 +871,10 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                     __builtin_amdgcn_s_barrier();  // all eight tail waves have put their blocks of the output tile into LDS
                     chain_gemm<BF>(a, smem, decode(0).m0, wave, lane, Cq);
                 }
-            } else
-                tail_gemm<BF, 3, true>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
+            } else {
+                tail_gemm<BF, 3, true, CHAIN>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
+                if constexpr (CHAIN) chain_narrow(a, smem, decode(0).m0, wave, lane);
+            }
         }
         if constexpr (BONE) {
             const Item it0 = decode(0);
@@ -1204,7 +1243,11 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                 }
             } else {
                 TailRegs<BF> T;
-                tail_gemm<BF, 1, false>(a, smem, it.m0, wm2, g2, 0, lane, T);
+                tail_gemm<BF, 1, false, CHAIN>(a, smem, it.m0, wm2, g2, 0, lane, T);
+                if constexpr (CHAIN) {  // the chain GEMM belongs to the producer waves; this wave only delivers its block
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
             }
             break;  // one tile per workgroup: nothing of the K-loop state (prefetched fragments, item bookkeeping) lives on
         }
@@ -1369,8 +1412,15 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
         if (a.tail_n > 0) {  // tail GEMM variant: one tile per workgroup, start / end stamps at most
             if (a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 64 || a.os != 1 || a.tail_n != 256 || !a.tail_w || !a.tail_bias)
                 return hipErrorInvalidValue;
+            // the 64-wide chain: bf16, behind a tail with shortcut + ReLU and bf16 output only
+            if (a.chain_n != 0 && (!a.bf16 || a.chain_n != 64 || !a.chain_w || !a.chain_bias || !a.chain_out || a.chain_ld < 64 || !a.resid ||
+                                   a.relu_cols < 256 || a.out_f32 || a.Nvalid != 256))
+                return hipErrorInvalidValue;
 #define LAUNCH_TAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, BF, PR, 1>), grid, dim3(512), lds, st, a)
-            if (a.bf16) {
+            if (a.bf16 && a.chain_n) {
+                if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, true, 0, 3>), grid, dim3(512), lds, st, a);
+                else hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, true, 1, 3>), grid, dim3(512), lds, st, a);
+            } else if (a.bf16) {
                 if (prof == 0) LAUNCH_TAIL(true, 0);
                 else LAUNCH_TAIL(true, 1);
             } else {
@@ -1463,6 +1513,7 @@ static hipError_t setup_stream()
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 1>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 1>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 0, true>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 0, true>);
+        fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 3>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 3>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 2>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 2>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 2>);
         static_assert(x3_lds() <= stream_lds<64, 64, 1, 5>(), "the split-product ring fits the same LDS allowance");

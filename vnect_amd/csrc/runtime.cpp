@@ -532,18 +532,23 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     // one call); in fp32 the chained layer is MFMA-bound either way (7.6 us of matrix work on the same four SIMDs) and the chain's own
     // overhead exceeds the launch it saves (-1.5 %).  VNECT_NO_CHAIN=1 / VNECT_FORCE_CHAIN=1: A/B runs and the fp32 form's parity test.
     if (chain_out) *chain_out = -1;
-    if (wide && cout == 512 && relu2 && !chain_scope.empty() && chain_out && !getenv("VNECT_NO_CHAIN") && (h->bf16 || getenv("VNECT_FORCE_CHAIN"))) {
-        const HostArray* Wn = get_w(h, chain_scope + "/weights", {1, 1, cout, 128});
-        const HostArray* Bn = Wn ? get_w(h, chain_scope + "/biases", {128}) : nullptr;
+    // The 64-wide tail chains too (res2a -> res2b_branch2a, 256 -> 64; conv.hip: chain_narrow), in bf16 only: its output tile would not
+    // fit the two-workgroups-per-CU ring in fp32.
+    const bool chain_wide = wide && cout == 512 && (h->bf16 || getenv("VNECT_FORCE_CHAIN"));
+    const bool chain_narrow = narrow && !wide && cout == 256 && h->bf16 && resid >= 0;
+    if ((chain_wide || chain_narrow) && relu2 && !chain_scope.empty() && chain_out && !getenv("VNECT_NO_CHAIN")) {
+        const int cn = chain_wide ? 128 : 64;
+        const HostArray* Wn = get_w(h, chain_scope + "/weights", {1, 1, cout, cn});
+        const HostArray* Bn = Wn ? get_w(h, chain_scope + "/biases", {cn}) : nullptr;
         if (!Bn) return -1;
         std::vector<float> w3, b3(Bn->d.begin(), Bn->d.end());
-        plan::pack_tail(Wn->d.data(), cout, 128, h->bf16, w3);
+        plan::pack_tail(Wn->d.data(), cout, cn, h->bf16, w3);
         float *dw3 = nullptr, *db3 = nullptr;
         if (upload_weights(h, &dw3, w3) || upload(h, &db3, b3)) return -1;
-        L.out3 = add_tensor(h, chain_scope, tin.S, ho, wo, 128, 128);
-        a.chain_w = dw3, a.chain_bias = db3, a.chain_n = 128, a.chain_ld = 128;
+        L.out3 = add_tensor(h, chain_scope, tin.S, ho, wo, cn, cn);
+        a.chain_w = dw3, a.chain_bias = db3, a.chain_n = cn, a.chain_ld = cn;
         L.name += ">" + chain_scope;
-        L.flops += 2.0 * a.M * (double)cout * 128;
+        L.flops += 2.0 * a.M * (double)cout * cn;
         *chain_out = L.out3;
     }
     h->layers.push_back(L);
@@ -666,12 +671,13 @@ int finalize_impl(vnect_handle* h)
     // not admit it (more than 512 tiles: four or more scales; per-layer read-back requested) the stand-alone layers run, and in
     // the reference's wiring res2b_branch2b / res2c_branch2b -- both read res2b_branch2a -- share one dual-output launch.
     int r;
+    int res2_chained = -1;  // the next block's branch2a where the tail launch of this one has produced it (chain GEMM, bf16)
     {
         int s = -1;
         int a = add_conv_pair(h, "res2a_branch2a", 64, "res2a_branch1", 256, pool1, 1, &s);
         NEED(a);
         bool fits = false;
-        r = add_conv_tail(h, "res2a_branch2b", "res2a_branch2c", a, s, "res2a", 64, 256, &fits);
+        r = add_conv_tail(h, "res2a_branch2b", "res2a_branch2c", a, s, "res2a", 64, 256, &fits, true, "res2b_branch2a", &res2_chained);
         if (!fits) {
             int b = conv("res2a_branch2b", a, 3, 1, 64, true);
             NEED(b);
@@ -682,10 +688,11 @@ int finalize_impl(vnect_handle* h)
     if (h->cfg.paper_res2c) {
         for (const char* p : {"res2b", "res2c"}) {
             const std::string P = p;
-            int a = conv(P + "_branch2a", r, 1, 1, 64, true);
+            int a = res2_chained >= 0 ? res2_chained : conv(P + "_branch2a", r, 1, 1, 64, true);
+            res2_chained = -1;
             NEED(a);
             bool fits = false;
-            int o = add_conv_tail(h, P + "_branch2b", P + "_branch2c", a, r, P, 64, 256, &fits);
+            int o = add_conv_tail(h, P + "_branch2b", P + "_branch2c", a, r, P, 64, 256, &fits, true, P == "res2b" ? "res2c_branch2a" : "", &res2_chained);
             if (!fits) {
                 int b = conv(P + "_branch2b", a, 3, 1, 64, true);
                 NEED(b);
@@ -698,7 +705,8 @@ int finalize_impl(vnect_handle* h)
         // vnect_model.py:50-57: res2c_branch2b consumes res2b_branch2a (`:56`), res2c_branch2a is dead and pruned
         if (!get_w(h, "res2c_branch2a/weights", {1, 1, 256, 64})) return VNECT_E_ARG;  // schema completeness, like the reference's load_weights
         const int x = r;
-        int a = conv("res2b_branch2a", x, 1, 1, 64, true);
+        int a = res2_chained >= 0 ? res2_chained : conv("res2b_branch2a", x, 1, 1, 64, true);
+        res2_chained = -1;
         NEED(a);
         bool fits = false;
         int r2b = add_conv_tail(h, "res2b_branch2b", "res2b_branch2c", a, x, "res2b", 64, 256, &fits);
