@@ -182,7 +182,9 @@ def test_conv_weight_packing_round_trip(hp):
     assert np.array_equal(P[:64], Wa[0, 0].T) and not P[64:].any() and np.array_equal(Q[64:88], Wb[0, 0].T) and not Q[:64].any()
     # tail GEMMs: (1,1,mid,cout) -> the MFMA's B-fragment order [column block][group q][lane = 32 hh + column][e], element
     # k = UQ q + UH hh + e of column 32 cb + column (fp32: UQ, UH = 8, 4; bf16: 16, 8); columns padded to whole blocks with zeros
-    for mid, cout, bf16 in ((64, 256, 0), (64, 256, 1), (128, 512, 0), (128, 512, 1), (128, 84, 0), (128, 84, 1)):
+    # (the tails' 1x1 layers; the chain GEMMs' -- next block's branch2a, 512 -> 128 and 256 -> 64; the stem's pair, 64 -> 64 + 256)
+    for mid, cout, bf16 in ((64, 256, 0), (64, 256, 1), (128, 512, 0), (128, 512, 1), (128, 84, 0), (128, 84, 1), (512, 128, 0), (512, 128, 1),
+                            (256, 64, 1), (64, 320, 0), (64, 320, 1)):
         Wt = rng.randn(1, 1, mid, cout).astype(np.float32)
         UQ, UH = (16, 8) if bf16 else (8, 4)
         nb, NQ = (cout + 31) // 32, mid // UQ
