@@ -144,8 +144,9 @@ def roofline(tim, nprof, precision, images_frac=1.0):
                   "achieved": round(flops / (exec_ms * 1e-3) / 1e12, 3),
                   "frac": round(flops / (exec_ms * 1e-3) / 1e12 / peak, 4)}
     common = dict(
-        kernel="vnect::conv_stream_kernel<BM,BN,KG,NS,%s,0> (implicit-GEMM conv on MFMA, LDS-DMA ring) + vnect::stem_kernel (conv1 + pool1 "
-               "[+ gen_input_batch] on spatial tiles): %d launches per frame" % ("true" if precision == "bf16" else "false", launches),
+        kernel="vnect::conv_stream_kernel<BM,BN,KG,NS,%s,0> (implicit-GEMM conv on MFMA, LDS-DMA ring; some launches carry a second / third "
+               "layer as tail / chain GEMMs) + vnect::stem_kernel (gen_input_batch + conv1 + pool1 + res2a's first 1x1 pair on spatial tiles): "
+               "%d launches per frame" % ("true" if precision == "bf16" else "false", launches),
         launches_per_frame=launches, avg_launch_us=round(conv_ms * 1e3 / launches, 3), first_to_last_wave=first_last,
         kernel_ms_per_frame=round(conv_ms, 4), flops_per_frame=flops,
         algorithmic_per_launch=(BF16_BYTES_PER_FRAME * images_frac / launches if precision == "bf16" else flops / launches),
