@@ -138,6 +138,9 @@ def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
         batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77 + len(scales), smooth=True), scales)
         outs, counts, joints = {}, {}, {}
         frame = helpers.synth_frame(91 + len(scales), 368, 300, smooth=True)
+        # (fp32 plans take the wide form from 128 workgroups on -- it is slower for a single scale's 67 --: VNECT_FORCE_WIDE_TAIL keeps
+        # that geometry under test)
+        monkeypatch.setenv("VNECT_FORCE_WIDE_TAIL", "1")
         for tag, env in (("default", {}), ("no_wide", {"VNECT_NO_WIDE_TAIL": "1"}), ("no_tail", {"VNECT_NO_TAIL": "1"}),
                          ("no_chain", {"VNECT_NO_CHAIN": "1"}), ("force_chain", {"VNECT_FORCE_CHAIN": "1"}),
                          ("no_stem_pair", {"VNECT_NO_STEM_PAIR": "1"})):
@@ -168,6 +171,12 @@ def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
         assert counts["no_chain"] == ((8, 8) if wide else (0, 0))
         assert counts["force_chain"] == ((8, 12 if prec == "bf16" else 11) if wide else (0, 0))  # bf16: the 64-wide tail of res2a chains too
         assert counts["default"] == counts["no_stem_pair"] == counts["force_chain" if prec == "bf16" else "no_chain"]
+        monkeypatch.delenv("VNECT_FORCE_WIDE_TAIL")
+        if S == 1 and prec == "fp32":  # the plan's own choice for one scale in fp32: the 92x92 tails only
+            h = _handle(scales, weights, precision=p)
+            assert sum(1 for L in h.layers() if ">" in L["name"]) == 3
+            assert np.array_equal(h.forward(batch), outs["no_wide"])
+            h.close()
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

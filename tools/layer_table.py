@@ -7,7 +7,8 @@ from vnect_amd import _native
 from vnect_amd.weights import synthetic_weights
 
 prec = _native.BF16 if os.environ.get("LT_BF16") == "1" else (_native.FP32_SPLIT if os.environ.get("LT_SPLIT") == "1" else _native.FP32)
-h = _native.Handle([1.0, 0.8, 0.6], precision=prec)
+scales = [float(x) for x in os.environ.get("LT_SCALES", "1.0,0.8,0.6").split(",")]  # LT_SCALES=1.0: the plan of a pyramid rank
+h = _native.Handle(scales, precision=prec)
 h.set_weights(synthetic_weights()); h.finalize()
 h.upload_frame(0, helpers.synth_frame(1234))
 for i in range(5):

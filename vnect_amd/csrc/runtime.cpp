@@ -490,7 +490,12 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
     const int EPR = h->bf16 ? 64 : 32;
     const long long pixels = (long long)tin.S * tin.H * tin.W;
     const bool narrow = mid == 64 && cout == 256 && (pixels + 63) / 64 <= 512;
-    const bool wide = mid == 128 && cout <= 512 && (pixels + 31) / 32 <= 256 && !h->x3 && !getenv("VNECT_NO_WIDE_TAIL") && !getenv("VNECT_FORCE_TILE");
+    // ... and at least half a chip of them in fp32: one scale at 46x46 is 67 workgroups, each alone with the whole 3x3 K loop where the
+    // stand-alone layer splits K over the idle CUs -- measured, single-scale handle (a pyramid rank): 0.670 ms per frame with the wide
+    // tails against 0.619 without; two scales (133): level; bf16: level at one scale, +5 % at two (tools/one_scale_ab.py).
+    const long long wide_wgs = (pixels + 31) / 32;
+    const bool wide = mid == 128 && cout <= 512 && wide_wgs <= 256 && (h->bf16 || wide_wgs >= 128 || getenv("VNECT_FORCE_WIDE_TAIL")) && !h->x3 &&
+                      !getenv("VNECT_NO_WIDE_TAIL") && !getenv("VNECT_FORCE_TILE");
     *fits = (narrow || wide) && tin.Cs % EPR == 0 && !h->keep_activations && !getenv("VNECT_NO_TAIL");
     if (!*fits) return -1;
     const int cin = tin.C;
