@@ -194,8 +194,9 @@ def test_fused_stem_is_bit_identical(weights, monkeypatch, prec):
     # (that form's host-side fallback: pyramid_kernel + the stem from the batch tensor)
     frames = [helpers.synth_frame(31, smooth=True), helpers.synth_frame(32, 538, 368, smooth=True), helpers.synth_frame(33, 240, 320),
               helpers.synth_frame(34, 368, 200), helpers.synth_frame(35, 123, 368, smooth=True), helpers.synth_frame(36)]
-    # [1.0, 0.3]: a scale whose tiles need more frame rows than the kernel's LDS rectangle holds (plan::stem_frame_fits -> fallback)
-    for scales in (BASELINE_SCALES, [1.0], [1, 0.85, 0.7, 0.5], [1.0, 0.4], [1.0, 0.3]):
+    # [1.0, 0.8, 0.3], [1.0, 0.15]: scales whose tiles need more frame rows than the kernel's LDS rectangle holds (plan::stem_frame_fits
+    # -> fallback); one and two images run 2- and 3-row tiles (hostplan.h: stem_groups), three 4- and 5-row ones
+    for scales in (BASELINE_SCALES, [1.0], [1, 0.85, 0.7, 0.5], [1.0, 0.4], [1.0, 0.3], [1.0, 0.8, 0.3], [1.0, 0.15]):
         plain = _handle(scales, weights, precision=p, keep_activations=True)
         assert [L["name"] for L in plain.layers()][:2] == ["conv1", "pool1"]
         batch, _, _ = oracle.gen_input_batch(frames[1], scales)

@@ -330,17 +330,19 @@ def test_stem_row_groups_and_frame_eligibility(hp):
     for S in range(1, 9):
         G = hp.hp_stem_groups(S, row0)
         r = list(row0[:G + 1])
-        assert r[0] == 0 and r[-1] == 92 and all(4 <= b - a <= 5 for a, b in zip(r, r[1:])), (S, r)
+        assert r[0] == 0 and r[-1] == 92 and all((4 if S >= 3 else 2) <= b - a <= 5 for a, b in zip(r, r[1:])), (S, r)
         if S <= 3:
             assert S * G * 4 <= 256     # one tile per CU, one round
-    assert hp.hp_stem_groups(3, row0) == 21
+    assert hp.hp_stem_groups(3, row0) == 21 and hp.hp_stem_groups(2, row0) == 32 and hp.hp_stem_groups(1, row0) == 46
 
     def fits(scales, bf16=0):
         s = np.array(scales + [1.0] * (8 - len(scales)), np.float64)
         return hp.hp_stem_frame_fits(_p(s, f64p), len(scales), 0, bf16)
     assert fits([1.0, 0.8, 0.6]) == 1 and fits([1, 0.85, 0.7]) == 1 and fits([1.0, 0.8, 0.6], 1) == 1 and fits([1.0, 0.5]) == 1
     assert fits([1.0, 0.4]) == 1        # (a tile only needs the part of its patch that lies inside the scaled image)
-    assert fits([1.0, 0.3]) == 0        # more frame rows than the kernel's LDS rectangle holds: the batch-tensor form runs instead
+    assert fits([1.0, 0.3]) == 1        # two images: 2- and 3-row tiles, whose patches need fewer frame rows
+    assert fits([1.0, 0.8, 0.3]) == 0   # three: 4- and 5-row tiles -- more frame rows than the kernel's LDS rectangle holds: the batch-tensor form runs instead
+    assert fits([1.0, 0.15]) == 0
 
 
 # ------------------------------------------------------------------------------------------ the same, sanitized

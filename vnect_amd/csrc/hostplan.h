@@ -404,13 +404,15 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
 }
 
 // ---- the fused stem's row groups (stem.hip) ------------------------------------------------------------
-// An image's 92 pooled rows in G groups of 4 and 5: as few tiles (S x G x 4) as one round over the 256 CUs allows (S = 3: G = 21 ->
-// 252 tiles), never more than 5 rows per tile (the LDS patch), never fewer than 4 (the halo rows are recomputed per tile).
+// An image's 92 pooled rows in G groups: as MANY tiles (S x G x 4) as one round over the 256 CUs allows (S = 3: G = 21 -> 252 tiles of 4
+// or 5 rows; S = 2: 32 groups of 2 or 3; S = 1: 46 of 2 -- a launch takes as long as its tiles do, so fewer images mean shorter tiles, not
+// idle CUs: round 3, a pyramid rank's stem 43.6 -> 36.9 us), never more than 5 rows per tile (the LDS patch), never fewer than 2 (every
+// tile recomputes one halo row), and for four or more images -- several rounds anyway -- the 4-and-5-row tiles with the least halo.
 // row0[g] = first row of group g, row0[G] = 92.  Returns G.
 inline int stem_groups(int S, unsigned char* row0)
 {
     int G = 256 / (4 * std::max(S, 1));
-    G = G < 19 ? 19 : (G > 23 ? 23 : G);
+    G = G < 19 ? 19 : (G > 46 ? 46 : G);
     const int base = 92 / G, rem = 92 % G;
     int r = 0;
     for (int g = 0; g < G; g++) row0[g] = (unsigned char)r, r += base + (g < rem ? 1 : 0);
