@@ -478,10 +478,10 @@ def main():
             "exchange": (("rccl: ncclAllGather of 710 976 B per rank" if args.exchange == "rccl" else "p2p: peer writes over xGMI")
                          if args.pyramid else None),
             "pyramid_p2p": pyramid_p2p,
-            # (a pyramid line is a latency configuration: one rank's single-scale frame costs 0.62 ms fp32 against 0.93 ms for all three
+            # (a pyramid line is a latency configuration: one rank's single-scale frame costs 0.60 ms fp32 against 0.93 ms for all three
             # scales on one GPU, tools/one_scale_rate.py / DESIGN section 6 -- it cannot beat three stream replicas on frames/s)
             "note": ((rehearsal_note + "; " if rehearsal_note else "") + "pyramid sharding buys latency, not throughput: a rank's single-scale "
-                     "frame is 0.62 ms fp32 (0.35 bf16) against 0.93 (0.40) for all three scales on one GPU (DESIGN section 6)") if args.pyramid else None,
+                     "frame is 0.60 ms fp32 (0.34 bf16) against 0.93 (0.40) for all three scales on one GPU (DESIGN section 6)") if args.pyramid else None,
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),

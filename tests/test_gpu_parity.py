@@ -161,10 +161,9 @@ def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
         for tag in outs:
             if S >= 3:  # the stand-alone layers run whole-K tiles like the fused ones: the same sums in the same order
                 assert np.array_equal(outs[tag], outs["no_tail"]), (scales, tag)
-            else:       # fewer scales: the stand-alone 3x3 layers split K (hostplan.h: choose_tile), so only the order of the sums differs
+            else:       # fewer scales: stand-alone 3x3 (and, for one scale, 1x1) layers split K (hostplan.h: choose_tile), so only the order of the sums differs
                 err = float(np.abs(outs[tag] - outs["no_tail"]).max() / np.abs(outs["no_tail"]).max())
                 assert err <= (2e-2 if prec == "bf16" else 1e-5), (scales, tag, err)
-                assert np.array_equal(outs[tag], outs["default"]) or tag in ("no_tail", "no_wide"), (scales, tag)
         assert counts["no_tail"] == (0, 0)
         assert counts["no_wide"] == ((3, 4 if prec == "bf16" else 3) if S <= 3 else (0, 0))  # the 92x92 tails: up to 512 tiles of 64 rows
         wide = S <= 3

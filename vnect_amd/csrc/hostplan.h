@@ -378,7 +378,8 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
     const int kel = K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
     const long long mt = (M + 63) / 64, nreal = Nreal;
     const long long tiles = mt * (round_up((int)nreal, 64) / 64) * nphase;
-    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096)) {
+    // (tiles <= 72 && K >= 512: a single scale's 1x1 layers at 46x46 -- a pyramid rank's plan: `res3*_branch2a` 10.1 -> 7.0 us as 64x32x2)
+    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096) || (tiles <= 72 && kel >= 512)) {
         // Too few 64x64 tiles for 256 CUs and a long K: split K.  Inside the workgroup where that alone fills the chip
         // (one workgroup per CU, four K-parallel or M/N-parallel accumulators: no slabs, no reduce launch) ...
         const long long t64x32 = mt * (round_up((int)nreal, 32) / 32) * nphase;
