@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- frames/s of 368x368, 3-scale VNect inference on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
@@ -35,6 +34,8 @@ PEAK_HBM = 8000.0              # GB/s
 # bf16 conv stack, algorithmic bytes per frame: bf16 weights 29.2 MB + every layer output written once and read once
 # (2 x 3 images x 58.7 MB of bf16 activations)
 BF16_BYTES_PER_FRAME = 29.2e6 + 2 * 3 * 58.7e6
+# committed rocprofv3 summaries are named profiles/rNN<prefix>_{kernel_stats.csv,conv_roofline.json,traffic.json} (tools/profile_round.sh)
+PROFILE_PREFIX = {"fp32": "", "bf16": "_bf16", "fp32_split": "_split"}
 
 
 def cpu_baseline(weights, budget_s):
@@ -58,6 +59,7 @@ def cpu_baseline(weights, budget_s):
             break
     cores = oracle.lib().vo_sgemm_threads()
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "implementation": "oracle/ (C + OpenMP restatement of the whole path, blocked AVX SGEMM)",
             "sample": "%d frames of the same workload in %.1f s (C/OpenMP fp32 oracle, AVX2/AVX-512 SGEMM, threads capped at 16 "
                       "of %d host cores: more are slower)" % (n, dt, len(os.sched_getaffinity(0)))}
 
@@ -103,7 +105,8 @@ def cpu_framework_baseline(weights, budget_s):
         dt = time.perf_counter() - t0
         if (dt >= budget_s and n >= 3) or n >= 400:
             break
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "proxy: torch-CPU (oneDNN) fp32 network + oracle pre/post",
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "implementation": "torch-CPU (oneDNN) fp32 restatement of the network (tests/torch_net.py) + the oracle's pre / post-processing",
             "thread_sweep_frames_per_s": sweep,
             "sample": "%d frames of the same workload in %.1f s on %d threads of %d host cores (torch %s; fastest of the sweep %s)"
                       % (n, dt, threads, ncores, torch.__version__, sweep)}
@@ -136,9 +139,12 @@ def roofline(tim, nprof, precision, images_frac=1.0):
     flops = tim["conv_flops"] * images_frac            # algorithmic FLOPs of the live launch plan (2 * MAC)
     launches = tim["conv_launches"]
     achieved = flops / (conv_ms * 1e-3) / 1e12
-    pre = {"fp32": "", "bf16": "_bf16"}.get(precision, "_" + precision)   # tools/profile_round.sh r02 / r02_bf16 -> r02_traffic.json / r02_bf16_traffic.json
+    # tools/profile_round.sh r02 / r02_bf16 / r03_split -> r02_traffic.json / r02_bf16_traffic.json / r03_split_traffic.json
+    pre = PROFILE_PREFIX[precision]
     traffic_frame, tfile = committed("%s_traffic.json" % pre, "hbm_bytes_per_frame")
     rocprof_us, rfile = committed("%s_conv_roofline.json" % pre, "conv_avg_us_per_launch")
+    rocprof_ms, _ = committed("%s_conv_roofline.json" % pre, "conv_ms_per_frame")
+    rocprof_calls, _ = committed("%s_conv_roofline.json" % pre, "conv_calls_per_frame")
     peak = PEAK_BF16_MFMA if precision == "bf16" else PEAK_FP32_MFMA
     first_last = {"avg_launch_us": round(exec_ms * 1e3 / launches, 3),
                   "achieved": round(flops / (exec_ms * 1e-3) / 1e12, 3),
@@ -155,7 +161,15 @@ def roofline(tim, nprof, precision, images_frac=1.0):
         # committed summary of an earlier run of this command, NOT a measurement of this run: the file says which round
         traffic=None if traffic_frame is None else round(traffic_frame / launches, 1),
         traffic_per_frame=traffic_frame, traffic_source=tfile,
-        rocprofv3_avg_launch_us=None if rocprof_us is None else round(rocprof_us, 3), rocprofv3_source=rfile)
+        rocprofv3_avg_launch_us=None if rocprof_us is None else round(rocprof_us, 3), rocprofv3_source=rfile,
+        # `frac` again from the committed rocprofv3 --kernel-trace --stats summary of this command alone (nothing live): the conv
+        # launches' total duration per frame there, this plan's algorithmic FLOPs, the same peak -- so the fraction can be checked
+        # from the line.  (The live `frac` above uses the profiling twin's slot times of THIS run and this box.)
+        recomputed_from=None if not rocprof_ms else {
+            "file": "profiles/" + rfile, "conv_ms_per_frame": round(rocprof_ms, 4), "conv_launches_per_frame": rocprof_calls,
+            "flops_per_frame": flops, "achieved_tflops": round(flops / (rocprof_ms * 1e-3) / 1e12, 3),
+            "frac_of_%s" % ("bf16_mfma_peak" if precision == "bf16" else "fp32_instruction_peak"): round(flops / (rocprof_ms * 1e-3) / 1e12 / peak, 4),
+            **({"hbm_frac": round(BF16_BYTES_PER_FRAME * images_frac / (rocprof_ms * 1e-3) / 1e9 / PEAK_HBM, 4)} if precision == "bf16" else {})})
     if precision == "fp32":  # the fp32 conv stack is MFMA-bound
         return dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_FP32_MFMA, unit="TFLOP/s",
                     frac=round(achieved / PEAK_FP32_MFMA, 4), **common)
@@ -190,10 +204,22 @@ def spawn_ranks(n, argv):
     worker script (the CPU test's stub)."""
     import socket
     import subprocess
+    worker = os.environ.get("VNECT_BENCH_WORKER") or os.path.abspath(__file__)
+    if (worker == os.path.abspath(__file__) and os.environ.get("VNECT_BENCH_BACKEND", "nccl") == "nccl"
+            and os.environ.get("VNECT_BENCH_DEVICE") is None):
+        # one rank per GPU: refuse at once -- before N processes meet in a rendezvous that can only time out -- when the machine
+        # has fewer devices than ranks.  Counted in a throw-away child, so that this parent still never touches the GPU.
+        try:
+            have = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                                      text=True, timeout=600).stdout.strip().splitlines()[-1])
+        except Exception:
+            have = None   # cannot tell: let the ranks find out (each checks its own device, see main)
+        if have is not None and have < n:
+            sys.exit("bench.py: --gpus %d needs %d HIP devices (one rank per GPU), this machine exposes %d: HIP device %d is missing"
+                     % (n, n, have, have))
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    worker = os.environ.get("VNECT_BENCH_WORKER") or os.path.abspath(__file__)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -251,6 +277,10 @@ def main():
                          "frame; default for N>1 is N independent streams (configs[4])")
     ap.add_argument("--exchange", choices=["rccl", "p2p"], default="rccl",
                     help="--pyramid: ncclAllGather over RCCL, or direct peer writes over xGMI (SURVEY 8e asks for both)")
+    ap.add_argument("--scales", default=None,
+                    help="comma-separated pyramid (default 1.0,0.8,0.6 = BASELINE.json).  Anything else is a REHEARSAL, labelled as such "
+                         "in the line: `--pyramid --scales 1.0 --gpus 1` runs the whole configs[3] machinery -- torch's \"nccl\" process "
+                         "group, PyramidJob, ncclCommInitRank + one ncclAllGather per frame, timed loop, profile -- with ONE rank on one GPU")
     ap.add_argument("--pyramid-both", action="store_true",
                     help="--pyramid with BOTH exchange forms in one job (rccl first, then p2p): the side-by-side SURVEY 8e asks for "
                          "from one 3-GPU lease; `value` is the RCCL all-gather form (the one north_star names), p2p under \"pyramid_p2p\"")
@@ -258,6 +288,12 @@ def main():
 
     if args.pyramid_both:
         args.pyramid = True
+    global SCALES
+    rehearsal_scales = None
+    if args.scales:
+        SCALES = [float(x) for x in args.scales.split(",") if x.strip()]
+        if SCALES != [1.0, 0.8, 0.6]:
+            rehearsal_scales = "rehearsal: scales %s instead of BASELINE.json's [1.0, 0.8, 0.6] -- not a measurement of any config" % SCALES
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus, sys.argv[1:])  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,10 +312,17 @@ def main():
     # VNECT_BENCH_BACKEND=gloo carries the barrier / max-reduce over the CPU (RCCL refuses two ranks on one device)
     backend = os.environ.get("VNECT_BENCH_BACKEND", "nccl")
     dev_override = os.environ.get("VNECT_BENCH_DEVICE")
-    torch.cuda.set_device(int(dev_override if dev_override is not None else os.environ.get("LOCAL_RANK", "0")))
-    grp = Group(backend)
+    want_dev = int(dev_override if dev_override is not None else os.environ.get("LOCAL_RANK", "0"))
+    have_dev = torch.cuda.device_count()
+    if want_dev >= have_dev:   # e.g. --gpus 2 under a launcher on a 1-GPU box: say which device is missing, at once, non-zero
+        sys.exit("bench.py: rank %s needs HIP device %d, but this machine exposes %d device(s) -- one rank per GPU (--gpus %d needs %d)"
+                 % (os.environ.get("RANK", "0"), want_dev, have_dev, args.gpus, args.gpus))
+    torch.cuda.set_device(want_dev)
+    # a pyramid job always builds the process group, with one rank too: the rehearsal then runs torch's RCCL and the library's in
+    # one process exactly as the 3-GPU job does
+    grp = Group(backend, always_init=args.pyramid, device=want_dev)
     rank = grp.rank
-    local_rank = int(dev_override) if dev_override is not None else grp.local_rank
+    local_rank = want_dev
     # what the run actually exercised: the world size as a real all-reduce over the backend sees it (backend "nccl" IS RCCL on
     # ROCm), and where every rank sits
     ranks_seen = grp.count_ranks()
@@ -305,14 +348,15 @@ def main():
     host_frames = [helpers.synth_frame(stream_seed(stream, k)) for k in range(nslots)]
     graph_mode = False if args.no_graph else (True if args.graph else "auto")
     job = None
-    rehearsal_note = None
+    rehearsal_note = rehearsal_scales
     if args.pyramid:
         if args.gpus != len(SCALES):
             sys.exit("--pyramid shards the %d scales over %d GPUs: use --gpus %d" % (len(SCALES), len(SCALES), len(SCALES)))
         if args.pyramid_both and dev_override is not None:
             # one-GPU rehearsal: RCCL refuses several ranks on one device ("invalid usage"), so only the peer-write leg can run here
             args.pyramid_both, args.exchange = False, "p2p"
-            rehearsal_note = "rehearsal on ONE device: the RCCL leg of --pyramid-both cannot run (RCCL refuses several ranks per device); p2p only"
+            rehearsal_note = ((rehearsal_note + "; ") if rehearsal_note else "") + \
+                "rehearsal on ONE device: the RCCL leg of --pyramid-both cannot run (RCCL refuses several ranks per device); p2p only"
         if args.pyramid_both:
             args.exchange = "rccl"   # first leg; the p2p leg follows the headline's timed region and profile
 
@@ -327,6 +371,13 @@ def main():
         h = make(args.precision, use_graph=graph_mode, lanes=3)
     for k in range(nslots):
         h.upload_frame(k, host_frames[k])
+    rccl_lib = None
+    if args.pyramid and args.exchange == "rccl":
+        path, reused = _native.Handle.comm_library()   # the file ncclAllGather lives in, and whether it is the copy torch had mapped
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        rccl_lib = {"path": path, "reused_the_copy_already_mapped": reused,
+                    "is_torchs_bundled_copy": os.path.exists(tl) and os.path.exists(path) and os.path.samefile(path, tl),
+                    "copies_mapped_in_this_process": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})}
 
     clock = [1.7e9]
 
@@ -456,11 +507,12 @@ def main():
             "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if args.pyramid else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16"}.get(args.precision, "f32 (products: 3-way bf16 split, 6 of 9 terms; fp32 accumulate)"), "data": "synthetic",
-            "config": {"workload": "368x368x3 uint8 BGR frame -> 21 joints; scales [1.0,0.8,0.6]; %s; batch 1 "
-                                   "(BASELINE.json configs[%d]); N>1 = N independent streams, one per GPU; frames resident in "
+            "config": {"workload": "368x368x3 uint8 BGR frame -> 21 joints; scales %s; %s; batch 1 "
+                                   "(BASELINE.json configs[%d]%s); N>1 = N independent streams, one per GPU; frames resident in "
                                    "HBM, the host-to-device copy of a frame is outside the timed region"
-                                   % {"fp32": ("fp32", 1), "bf16": ("bf16 operands, fp32 accumulate", 2)}.get(
-                                       args.precision, ("fp32 tensors / accumulators, split-product matrix work (VNECT_FP32_SPLIT)", 1)),
+                                   % ((json.dumps(SCALES).replace(" ", ""),) + {"fp32": ("fp32", 1), "bf16": ("bf16 operands, fp32 accumulate", 2)}.get(
+                                       args.precision, ("fp32 tensors / accumulators, split-product matrix work (VNECT_FP32_SPLIT)", 1))
+                                      + (" -- REHEARSAL at other scales" if rehearsal_scales else ("; configs[3] sharding" if args.pyramid else ""),)),
                        "weights": "seeded synthetic (reference ships none)", "frames_resident_in_hbm": True,
                        "h2d_in_timed_region": False,
                        "hip_graph": {False: "off (eager launches)", True: "on (every frame replays the graph)",
@@ -478,10 +530,15 @@ def main():
             "exchange": (("rccl: ncclAllGather of 710 976 B per rank" if args.exchange == "rccl" else "p2p: peer writes over xGMI")
                          if args.pyramid else None),
             "pyramid_p2p": pyramid_p2p,
-            # (a pyramid line is a latency configuration: one rank's single-scale frame costs 0.60 ms fp32 against 0.93 ms for all three
-            # scales on one GPU, tools/one_scale_rate.py / DESIGN section 6 -- it cannot beat three stream replicas on frames/s)
-            "note": ((rehearsal_note + "; " if rehearsal_note else "") + "pyramid sharding buys latency, not throughput: a rank's single-scale "
-                     "frame is 0.60 ms fp32 (0.34 bf16) against 0.93 (0.40) for all three scales on one GPU (DESIGN section 6)") if args.pyramid else None,
+            # (a pyramid line is a latency configuration: one rank's single-scale frame against the three-scale frame on one GPU is in
+            # the newest committed profiles/rNN_one_scale_rate.json -- tools/one_scale_rate.py, DESIGN section 6 -- never a literal here)
+            "note": "; ".join(x for x in (
+                rehearsal_note,
+                ("pyramid sharding buys latency, not throughput: what ONE rank does per frame against all three scales on one GPU is "
+                 "`one_scale_vs_three` (DESIGN section 6)") if args.pyramid else None) if x) or None,
+            "one_scale_vs_three": (dict(zip(("ms_per_frame", "source"), committed("_one_scale_rate.json", "ms_per_frame")))
+                                   if args.pyramid else None),
+            "rccl_library": rccl_lib,
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
@@ -538,11 +595,21 @@ def main():
 
     if rank == 0:
         if args.cpu_seconds > 0 and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(weights, args.cpu_seconds)
+            # `cpu_baseline` is the FASTEST honest CPU implementation of the same workload this box can run: the reference's TF-CPU path
+            # cannot run at all (no TF1, no weights), so both candidates are stand-ins and say so -- the C/OpenMP port of the path (the
+            # oracle; always kept under `cpu_baseline_port`) and the torch-CPU / oneDNN network with the oracle's pre / post-processing
+            # around it (`cpu_baseline_framework`).  Whichever is faster is the parsed key.
+            port = cpu_baseline(weights, args.cpu_seconds)
+            port["stands_in_for"] = "the reference's TF-CPU path, which cannot run here (no TensorFlow 1.x, no weights)"
+            out["cpu_baseline_port"] = port
             try:
-                out["cpu_baseline_framework"] = cpu_framework_baseline(weights, min(args.cpu_seconds, 8.0))
+                fw = cpu_framework_baseline(weights, min(args.cpu_seconds, 8.0))
+                fw["stands_in_for"] = port["stands_in_for"]
             except Exception as e:  # noqa: the proxy is optional evidence, the bench line is not
-                out["cpu_baseline_framework"] = {"error": str(e)[:200]}
+                fw = {"error": str(e)[:200]}
+            out["cpu_baseline_framework"] = fw
+            out["cpu_baseline"] = dict(fw if fw.get("value", 0) > port["value"] else port)
+            out["cpu_baseline"]["chosen_as"] = "the faster of cpu_baseline_port and cpu_baseline_framework on this box"
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VNECT_ABI_VERSION 3
+#define VNECT_ABI_VERSION 4
 #define VNECT_MAX_SCALES 8
 #define VNECT_MAX_STREAMS 4 /* independent video streams one handle can serve (vnect_submit_stream) */
 #define VNECT_BOX 368      /* src/estimator.py:19 box_size   */
@@ -207,6 +207,12 @@ int vnect_get_layer_stamps(vnect_handle* h, int idx, uint64_t* out24);
  * handle takes ONE image (its scale). */
 int vnect_comm_unique_id(void* id128);
 int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128);
+/* Which RCCL the library resolved, and how: the file ncclAllGather lives in (dladdr) goes to path_out (NUL-terminated, truncated to
+ * capacity); *reused_out = 1 when a copy the process had mapped already was reused -- the caller's torch.distributed "nccl" backend
+ * loads torch's bundled librccl.so; the reference has no counterpart (its one process owns one TF session,
+ * run_estimator_ps.py:35-36, 120-129) -- and 0 when the library opened librccl.so.1 itself.  VNECT_RCCL_LIB overrides the choice.
+ * Loads RCCL if it is not loaded yet (VNECT_E_COMM if there is none). */
+int vnect_comm_library(char* path_out, int capacity, int32_t* reused_out);
 /* The same exchange by plain peer writes over xGMI instead of RCCL (vnect_config::exchange = VNECT_XCHG_P2P; SURVEY 8e asks for
  * both, measured side by side: 711 KB per rank is ~4.6 us of wire time, a collective's launch + sync latency is tens of us).
  * Every rank exports a 128-byte blob describing its exchange block (IPC memory handle + the address inside the exporting

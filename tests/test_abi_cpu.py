@@ -130,3 +130,39 @@ def test_product_never_touches_the_oracle():
     # there is no CPU fallback either: the loader raises if the library is missing instead of substituting anything
     src = open(os.path.join(pkg, "_native.py")).read()
     assert "raise" in src and "oracle" not in src
+
+
+def test_rccl_copy_already_mapped_is_reused(tmp_path):
+    """vnect_comm_library / load_rccl (runtime.cpp): a process that has a librccl.so mapped already -- torch.distributed's "nccl"
+    backend maps torch's bundled copy -- gets THAT copy (RTLD_NOLOAD: no second RCCL build in the process, nothing RTLD_GLOBAL);
+    a process without one gets the ROCm copy through the library's RUNPATH.  Symbol lookup only: no GPU needed.  The same on the
+    GPU with real communicators: tests/test_gpu_multirank.py."""
+    import json
+    import subprocess
+    import sys
+    try:
+        import torch
+    except Exception:
+        pytest.skip("no torch: no bundled librccl.so to map first")
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(bundled):
+        pytest.skip("torch ships no librccl.so")
+    code = ("import ctypes, json, sys\nsys.path.insert(0, %r)\n"
+            "if sys.argv[1] != '-': ctypes.CDLL(sys.argv[1])\n"
+            "from vnect_amd import _native\np, r = _native.Handle.comm_library()\n"
+            "print(json.dumps({'path': p, 'reused': r, 'mapped': sorted({l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l})}))" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "VNECT_RCCL_LIB"}
+
+    def run(first):
+        r = subprocess.run([sys.executable, "-c", code, first], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    a = run(bundled)
+    assert a["reused"] is True and os.path.samefile(a["path"], bundled) and len(a["mapped"]) == 1, a
+    b = run("-")
+    assert b["reused"] is False and "librccl.so" in b["path"] and not os.path.samefile(b["path"], bundled) and len(b["mapped"]) == 1, b
+    # an explicit choice wins over both
+    r = subprocess.run([sys.executable, "-c", code, "-"], capture_output=True, text=True, env=dict(env, VNECT_RCCL_LIB=bundled), timeout=300)
+    c = json.loads(r.stdout.strip().splitlines()[-1])
+    assert os.path.samefile(c["path"], bundled) and c["reused"] is False, c

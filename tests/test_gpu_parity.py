@@ -767,11 +767,16 @@ def test_pyramid_shards_reassemble(weights, oracle_net):
         h.close()
 
 
-def test_pyramid_p2p_missing_peer_fails_the_frame(weights, monkeypatch):
-    """A rank whose peers never show up must get VNECT_E_COMM from the frame after the bounded wait -- never a hang."""
+@pytest.mark.parametrize("two_launches", [False, True])
+def test_pyramid_p2p_missing_peer_fails_the_frame(weights, monkeypatch, two_launches):
+    """A rank whose peers never show up must get VNECT_E_COMM from the frame after the bounded wait -- never a hang.  Both forms of
+    the post-processing honour the failed-exchange word (post_kernel, and joints_kernel behind VNECT_NO_POST_MERGE=1): the frame's
+    joints stage is skipped on the device, so the filter banks do not advance on stale maps."""
     from tests import helpers
     n = _native()
     monkeypatch.setenv("VNECT_XCHG_SPINS", "20000")
+    if two_launches:
+        monkeypatch.setenv("VNECT_NO_POST_MERGE", "1")
     ranks = [n.Handle([1.0, 0.7], pyramid=(r, 2), exchange=n.XCHG_P2P) for r in range(2)]
     for h in ranks:
         h.set_weights(weights)
@@ -931,7 +936,8 @@ def test_bf16_path_gated_against_fp32(weights, oracle_net, h3):
     for j in range(21):
         up = oracle.resize(np.ascontiguousarray(avg_f[:, :, j]), 8.0)
         assert up[int(raw_b[j, 0]), int(raw_b[j, 1])] >= up.max() - 2 * eps, j
-    assert close.sum() >= 15, "bf16 moved %d of 21 joints by more than one heat-map cell" % (21 - close.sum())
+    # (no "most joints within one cell" floor here: where a heat-map HAS a maximum -- a margin over every other cell that bf16 noise
+    # cannot bridge -- the bf16 arg-max must sit in the fp32 cell, for every such joint: test_bf16_margin_conditioned_joints)
     if same[14]:
         assert np.all(d3[same] <= bound3)
     assert float(np.abs(mb - mf).max()) <= 3e-2 * float(np.abs(mf).max())
@@ -987,8 +993,8 @@ def test_bf16_benchmarked_plan_parity(weights, oracle_net, h3):
         if k == 0:  # first frame: the filters are the identity, so joints_2d ARE the arg-max positions
             scaler = 368.0 / max(H, W)
             worst_close = min(worst_close, int(np.all(np.abs(j2a - j2f) <= 8.0 / scaler + 1e-9, axis=1).sum()))
-    print("bf16 arena plan: worst frame has %d/21 joints within one cell of fp32 (noise heat-maps)" % worst_close)
-    assert worst_close >= 15
+    print("bf16 arena plan: worst frame has %d/21 joints within one cell of fp32 (noise heat-maps; informational -- the gate is the "
+          "2-eps rule above and test_bf16_margin_conditioned_joints)" % worst_close)
     # (3) planted peaks: the post-processing of bf16-rounded maps against the fp32 maps
     for seed in (5, 6, 7):
         maps = helpers.synth_maps(seed, 3)
@@ -998,6 +1004,81 @@ def test_bf16_benchmarked_plan_parity(weights, oracle_net, h3):
         b2, b3 = fused.postprocess(maps, T0, T0 + 0.001)
         assert np.all(np.abs(a2 - b2) <= 8.0), seed       # 21/21 within one heat-map cell (oracle on the same maps: 0, 1 and 7 px)
     fused.close(), plain.close()
+
+
+def _cell_margin(up, rc):
+    """Margin of a heat-map maximum: the maximum of the x8-upsampled map (utils.py:153-175 takes its arg-max) minus the best value
+    OUTSIDE the 8x8 block of pixels -- one heat-map cell -- that holds it."""
+    r0, c0 = (int(rc[0]) // 8) * 8, (int(rc[1]) // 8) * 8
+    rest = up.copy()
+    rest[r0:r0 + 8, c0:c0 + 8] = -np.inf
+    return float(up[int(rc[0]), int(rc[1])] - rest.max())
+
+
+def test_bf16_margin_conditioned_joints(weights, h3):
+    """What the bf16 path owes the joints, THROUGH the bf16 net (utils.py:153-219 semantics).  Heat-maps of random weights are noise-like, so
+    an arg-max may legally jump between near-equal cells -- but not where the fp32 heat-map has a real maximum.  Over 16 frames (square,
+    the test picture's 538x368, landscape, portrait) and every joint:
+
+      * map gate: |bf16 maps - fp32 maps| <= eps = 3e-2 * max|fp32 maps| (every frame);
+      * margin-conditioned exactness: every (frame, joint) whose fp32 maximum beats the best value outside its own heat-map cell by more
+        than 2 eps -- merge and x8 upsample are convex blends, so bf16 noise cannot bridge that -- must have its bf16 arg-max IN THAT CELL:
+        ALL of them, and there must be at least 20 such pairs for the statement to mean something;
+      * joints_3d, every joint of every frame: the bf16 handle's read-off against the FP32 location maps read at the same (bf16) pixels
+        -- root row included -- within the bound the map gate implies (2 eps x 100 mm, times the read-off's extrapolation weights at the
+        borders); and where the pixel AND the root's pixel equal the fp32 path's, against the fp32 path's joints_3d.
+    No floor of the kind "most joints within one cell" is left."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    hb = _handle(BASELINE_SCALES, weights, precision=n.BF16)         # the arena plan bench.py times
+    shapes = [(368, 368), (538, 368), (240, 320), (368, 300)]
+    pairs, held, rows = 0, 0, []
+    worst3, worst_gap_ratio = 0.0, 0.0
+    for k in range(16):
+        H, W = shapes[k % 4]
+        frame = helpers.synth_frame(91000 + k, H, W, smooth=True)
+        t = T0 + 900 + k
+        hb.reset_filters(), h3.reset_filters()                      # first frame of a stream: the filters are the identity
+        j2b, j3b = hb.infer(frame, t, t + 0.001)
+        mb = hb.activation("res5c_branch2c")
+        j2f, j3f = h3.infer(frame, t, t + 0.001)
+        mf = h3.activation("res5c_branch2c")
+        top = float(np.abs(mf).max())
+        eps = 3e-2 * top
+        assert float(np.abs(mb - mf).max()) <= eps, k
+        avg_f, avg_b = oracle.merge_scales(mf, BASELINE_SCALES), oracle.merge_scales(mb, BASELINE_SCALES)
+        raw_f, raw_b = oracle.extract_2d(avg_f[0]), oracle.extract_2d(avg_b[0])
+        for j in range(21):
+            up = oracle.resize(np.ascontiguousarray(avg_f[0][:, :, j]), 8.0)
+            assert up[int(raw_b[j, 0]), int(raw_b[j, 1])] >= up.max() - 2 * eps, (k, j)          # the 2-eps rule, every joint
+            gap = _cell_margin(up, raw_f[j])
+            worst_gap_ratio = max(worst_gap_ratio, gap / eps)
+            if gap > 2 * eps:
+                pairs += 1
+                same_cell = bool(np.all(raw_b[j] // 8 == raw_f[j] // 8))
+                held += same_cell
+                rows.append((k, j, gap / eps, same_cell))
+                assert same_cell, "frame %d joint %d: margin %.2f eps, bf16 arg-max %s left the fp32 cell of %s" % (k, j, gap / eps, raw_b[j], raw_f[j])
+        # joints_3d: the bf16 read-off against the fp32 location maps at the bf16 pixels (first frame: unfiltered positions)
+        at_b = oracle.extract_3d(raw_b, avg_f[1], avg_f[2], avg_f[3])
+        own = oracle.extract_3d(raw_b, avg_b[1], avg_b[2], avg_b[3])
+        assert np.array_equal(own, j3b), k           # the GPU's post-processing of its own maps is exact arithmetic
+        # read-off weights: convex inside; a pixel left of 3.5 extrapolates with weights (1 + a, -a), a <= 7/16, per axis
+        amp = 1.0 + 2 * (7.0 / 16)
+        bound3 = 2 * (eps * 100) * amp * amp
+        d3 = float(np.abs(j3b.astype(np.float64) - at_b).max())
+        worst3 = max(worst3, d3 / bound3)
+        assert d3 <= bound3, (k, d3, bound3)
+        same_px = np.all(raw_b == raw_f, axis=1)
+        if same_px[14]:
+            assert np.all(np.abs(j3b - j3f)[same_px] <= bound3), k
+    _log("bf16_margin_pairs.json", {"pairs": pairs, "held": held, "max_margin_over_eps": worst_gap_ratio, "worst_3d_over_bound": worst3,
+                                    "rows": rows})
+    print("bf16 margin gate: %d (frame, joint) pairs with a margin > 2 eps out of %d, all %d in the fp32 cell; largest margin %.1f eps; "
+          "3-D read-off at most %.2f of its bound" % (pairs, 16 * 21, held, worst_gap_ratio, worst3))
+    assert pairs >= 20, "only %d pairs with a real maximum: pick other seeds" % pairs
+    hb.close()
 
 
 # ------------------------------------------------------------------------------------------ split-product fp32 path

@@ -7,6 +7,7 @@ no-exception-crosses-the-boundary promise of include/vnect_abi.h.
 import ctypes as C
 import os
 import pickle
+import re
 
 import numpy as np
 import pytest
@@ -216,6 +217,71 @@ def test_init_box_on_the_gpu_vs_oracle(weights, oracle_net):
     est.close(), fresh.close()
 
 
+# ------------------------------------------------------------------------------------------ joints -> angles, rendering (f4)
+def test_angles_and_rendering_from_gpu_joints(weights, oracle_net, tmp_path):
+    """SURVEY 8(f) rank 4 on the GPU: 24 frames of a synthetic video through VNectEstimator -> Joints2Angles (filtered, scripted
+    clock; src/joints2angles.py:23-109) against the oracle chain -> Joints2Angles, and draw_limbs_2d / draw_limbs_3d
+    (src/utils.py:222-244) of the GPU's joints written to files on the GPU box.
+
+    The consumer is a pure function of joints_3d plus its own eight OneEuro filters, so the gate is the estimator's: (1) the oracle's
+    post-processing of the GPU's OWN maps reproduces the GPU joints bit for bit, hence the eight angles bit for bit, every frame,
+    through both filter chains; (2) against the full oracle chain (oracle maps) the angles agree to 1e-3 rad on every frame up to the
+    first heat-map tie among the joints the formulas read (shoulders, elbows, wrists: 2..7, and the root 14 that every row has
+    subtracted) -- beyond a tie the filter states legitimately differ."""
+    import oracle
+    from vnect_amd import VNectEstimator, render
+    from vnect_amd.angles import Joints2Angles
+    from tests import helpers
+    scales = BASELINE_SCALES
+    est = _est(weights, scales=scales)
+    post = oracle.OracleEstimator(scales=scales)                      # GPU maps -> oracle joints (lockstep filters)
+    full = oracle.OracleEstimator(scales=scales, net=oracle_net)      # the oracle's whole __call__
+    ang_gpu, ang_post, ang_full = Joints2Angles(filter=True), Joints2Angles(filter=True), Joints2Angles(filter=True)
+    arm = [2, 3, 4, 5, 6, 7, 14]
+    clean, compared, worst = True, 0, 0.0
+    H, W = 400, 368
+    for k in range(24):
+        frame = helpers.synth_frame(6100 + k // 3, H, W, smooth=True)   # a new picture every third frame: the filters see motion and rest
+        t = T0 + 700 + k / 30 + 0.001 * (k % 5)                         # irregular clock
+        j2, j3 = est(frame, timestamp=(t, t + 0.0007))
+        maps = est.handle.activation("res5c_branch2c")
+        batch, scaler, (ox, oy) = oracle.gen_input_batch(frame, scales)
+        p2, p3 = post.postprocess(maps, t, t + 0.0007, scaler, ox, oy)
+        assert np.array_equal(j2, p2) and np.array_equal(j3, p3), k
+        a_gpu, a_post = ang_gpu(j3, timestamp=t + 0.002), ang_post(p3, timestamp=t + 0.002)
+        assert np.array_equal(np.array(a_gpu), np.array(a_post)), k                                    # (1)
+        assert len(a_gpu) == 8 and np.all(np.isfinite(a_gpu)), k
+        ref_maps = oracle_net.forward(batch)
+        r2, r3 = full.postprocess(ref_maps, t, t + 0.0007, scaler, ox, oy)
+        a_full = ang_full(r3, timestamp=t + 0.002)
+        raw_g = oracle.extract_2d(oracle.merge_scales(maps, scales)[0])
+        raw_r = oracle.extract_2d(oracle.merge_scales(ref_maps, scales)[0])
+        clean = clean and bool(np.array_equal(raw_g[arm], raw_r[arm]))
+        if clean:                                                                                     # (2)
+            d = float(np.abs(np.array(a_gpu) - np.array(a_full)).max())
+            worst, compared = max(worst, d), compared + 1
+            assert d <= 1e-3, (k, d)
+    assert compared >= 1
+    print("angles: %d/24 frames compared with the full oracle chain (before the first tie on an arm joint), worst |d| %.3g rad" % (compared, worst))
+    # rendering of the GPU's joints to files on this box
+    img = render.draw_limbs_2d(frame, j2, VNectEstimator.joint_parents, [0, 0, W - 1, H - 1])
+    assert img.shape == frame.shape and img.dtype == np.uint8 and np.any(img != frame)
+    r, c = (j2[2] + j2[1]) / 2                                         # middle of limb 2 -> 1
+    if 3 <= r < H - 3 and 3 <= c < W - 3:
+        assert tuple(img[int(round(r)), int(round(c))]) in (render.LIMB_BGR, render.RECT_BGR)
+    v3 = render.draw_limbs_3d(j3, VNectEstimator.joint_parents)
+    assert v3.shape == (400, 400, 3) and np.any(v3 != 255)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, pic in (("f4_limbs_2d.png", img), ("f4_limbs_3d.png", v3)):
+        for d in (str(tmp_path), out_dir):
+            render.save(os.path.join(d, name), pic)
+        from PIL import Image
+        back = np.asarray(Image.open(os.path.join(str(tmp_path), name)))[:, :, ::-1]
+        assert np.array_equal(back, pic), name
+    est.close()
+
+
 # ------------------------------------------------------------------------------------------ static gen_input_batch (a10)
 def test_static_gen_input_batch_needs_no_weights(weights):
     """VNectEstimator.gen_input_batch is a @staticmethod in the reference (estimator.py:70-81): it runs on a pre-processing-only
@@ -400,8 +466,21 @@ def test_bench_line_contract():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.2 < rf["frac"] < 1.0 and 30 <= rf["launches_per_frame"] <= 45 and "traffic" in rf
+    # `frac` again from the committed rocprofv3 summary alone: the file exists, and its numbers reproduce the fraction it states
+    rc = rf["recomputed_from"]
+    assert os.path.exists(os.path.join(root, rc["file"])) and rc["file"] == "profiles/" + rf["rocprofv3_source"]
+    assert abs(rc["achieved_tflops"] - rc["flops_per_frame"] / (rc["conv_ms_per_frame"] * 1e-3) / 1e12) < 0.01
+    assert abs(rc["frac_of_fp32_instruction_peak"] - rc["achieved_tflops"] / 157.3) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # the parsed key is the FASTER of the two honest CPU implementations; the C port stays beside it
+    port, fw = d["cpu_baseline_port"], d["cpu_baseline_framework"]
+    assert port["kind"] == "port" and "cannot run" in port["stands_in_for"] and cb["value"] == max(port["value"], fw.get("value", 0))
+    # every leg finds ITS committed profile (the split leg's files are profiles/rNN_split_*)
+    for leg, pre in ((d, ""), (d["bf16"], "_bf16"), (d["fp32_split"], "_split")):
+        r = leg["roofline"]
+        assert r["traffic_source"] and re.match(r"r\d\d%s_traffic\.json$" % pre, r["traffic_source"]), (pre, r["traffic_source"])
+        assert r["rocprofv3_source"] and re.match(r"r\d\d%s_conv_roofline\.json$" % pre, r["rocprofv3_source"]), (pre, r["rocprofv3_source"])
     assert d["bf16"]["dtype"] == "bf16" and d["bf16"]["value"] > d["value"] and d["bf16"]["roofline"]["bound"] == "hbm"
     assert d["fp32_split"]["value"] > 0 and d["fp32_split"]["roofline"]["bound"] == "mfma"
     assert d["rccl_ranks"] == 1 and d["ranks"][0]["device"] == 0 and d["launched_by"] == "single process"

@@ -187,3 +187,58 @@ def test_bench_spawns_its_own_ranks(tmp_path):
 def test_bench_spawner_reports_the_worst_return_code(tmp_path):
     r = _run_bench_bare(tmp_path, {"STUB_FAIL_RANK": "1"})
     assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+
+
+def test_bench_more_ranks_than_devices_fails_at_once():
+    """`python bench.py --gpus 2` (no launcher, backend "nccl") on a machine with fewer than 2 HIP devices -- this container has none,
+    a one-GPU box has one: non-zero exit at once, the message names the missing device, no rank is started, nothing on stdout.
+    Under a launcher's environment the rank itself refuses.  (The GPU-box twin is tests/test_gpu_multirank.py.)"""
+    import time
+    try:
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if have >= 2:
+        import pytest
+        pytest.skip("two devices here")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "VNECT_BENCH_BACKEND",
+                                                            "VNECT_BENCH_DEVICE", "VNECT_BENCH_WORKER")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout)
+    assert "HIP device %d is missing" % have in r.stderr and "exposes %d" % have in r.stderr, r.stderr[-1500:]
+    assert time.time() - t0 < 120
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode != 0 and "needs HIP device 1" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-1500:])
+
+
+def test_one_rank_process_group_on_request():
+    """Group(always_init=True) builds the process group for a world of ONE too (what a one-rank pyramid rehearsal needs: the same
+    all-reduce / broadcast code path as the 3-rank job), and a one-scale PyramidJob connects through it."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+from vnect_amd.parallel import Group, PyramidJob
+g = Group("gloo", always_init=True)
+assert g.world == 1 and g._dist is not None and g.count_ranks() == 1 and g.max_over_ranks(2.5) == 2.5
+calls = []
+class H:
+    @staticmethod
+    def comm_unique_id(): return b"u" * 128
+    def comm_init(self, r, w, uid): calls.append(("comm_init", r, w, uid))
+    def upload_frame(self, k, f): calls.append(("upload", k))
+    def infer_resident(self, slot, a, b): calls.append(("infer", slot)); return slot, None
+job = PyramidJob(g, [1.0], lambda r, w, ex: H(), "rccl")
+assert calls == [("comm_init", 0, 1, b"u" * 128)] and job.scale == 1.0
+job.upload(["f0", "f1"]); out, t = job.run(3, 2, 10.0)
+assert [c for c in calls if c[0] == "infer"] == [("infer", 0), ("infer", 1), ("infer", 0)]
+g.close()
+print("ok")
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

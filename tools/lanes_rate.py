@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Pipelined frame rate of ONE stream against the number of lanes (frames in flight); runs on the GPU box.
 Usage: python tools/lanes_rate.py [fp32|bf16]"""
 import os, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Print the per-layer launch plan and HIP-event times (tuning aid; runs on the GPU box)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

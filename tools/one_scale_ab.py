@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Frame time of 1- and 2-scale handles with and without the wide tail / chain forms (are they right for FEWER workgroups than CUs?)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-layer timeline of the conv kernels from the device-clock phase stamps (tuning aid; runs on the GPU box).
 
 Columns (us, medians over frames): kernel = earliest workgroup start .. latest workgroup end; gap = previous conv kernel's

@@ -1,7 +1,11 @@
-#!/usr/bin/env python3
 """Is post_kernel bound by cold instruction fetch?  The same launch back to back (vnect_postprocess in a loop: nothing else runs on
-the GPU in between, so the instruction cache stays warm) against its time inside a frame (profiles/*kernel_stats.csv).  Run under
-rocprofv3 --kernel-trace --stats; compare the post_kernel average."""
+the GPU in between, so the instruction cache stays warm) against its time inside a frame (profiles/*kernel_stats.csv).  Run as
+
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/post_warm -- python3 $GRAFT_REPO_ROOT/tools/post_warm.py
+
+(the interpreter itself after `--`: this file has no `#!/usr/bin/env` line on purpose -- under rocprofv3 the preloaded profiler has
+initialised the GPU before the program starts, and every exec hop behind that (env, bash -c, a launcher) is refused on this pool);
+compare the post_kernel average."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

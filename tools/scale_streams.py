@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Tuning aid: one frame's 3 scales as 3 concurrent single-image pipelines (one handle + host thread each) vs the batched S=3 handle."""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

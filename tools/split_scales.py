@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Tuning aid: one frame's scales split over two concurrent handles (timing only: each handle post-processes its own scales)."""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Map a rocprofv3 --kernel-trace CSV of tools/layer_table.py (or bench.py) onto the layer plan.
 
 usage: trace_layers.py <kernel_trace.csv> [frames_to_skip]

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Tuning aid: throughput of K independent streams (handles) sharing ONE GPU, each driven by its own host thread."""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

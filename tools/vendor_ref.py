@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """What the vendor libraries reach on the SAME layers (calibration for DESIGN.md / profiles, never part of the product):
 every conv-type layer of the VNect graph at batch 3 (scales [1.0, 0.8, 0.6] -> three 368x368 images), fp32,
 

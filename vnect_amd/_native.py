@@ -15,7 +15,7 @@ _lib = None
 
 MAX_SCALES = 8
 OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM, E_TIMEORDER, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_STREAMS = 4
 XCHG_RCCL, XCHG_P2P = 0, 1
 FP32, BF16, FP32_SPLIT = 0, 1, 2
@@ -79,6 +79,7 @@ SYMBOLS = {
     "vnect_get_layer_stamps": (C.c_int, [_H, C.c_int, C.POINTER(C.c_uint64)]),
     "vnect_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vnect_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "vnect_comm_library": (C.c_int, [C.c_char_p, C.c_int, _i32p]),
     "vnect_comm_p2p_export": (C.c_int, [_H, C.c_void_p]),
     "vnect_comm_p2p_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -256,6 +257,15 @@ class Handle:
         if rc:
             raise VnectError(rc, lib().vnect_last_error(None).decode())
         return bytes(buf)
+
+    @staticmethod
+    def comm_library():
+        """(path of the RCCL the library resolved, True if it reused a copy the process had mapped already -- torch's)."""
+        buf, reused = C.create_string_buffer(1024), C.c_int32(-1)
+        rc = lib().vnect_comm_library(buf, len(buf), C.byref(reused))
+        if rc:
+            raise VnectError(rc, lib().vnect_last_error(None).decode())
+        return buf.value.decode(), bool(reused.value)
 
     def comm_init(self, rank, nranks, unique_id):
         buf = (C.c_char * 128).from_buffer_copy(unique_id)

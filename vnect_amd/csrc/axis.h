@@ -1,13 +1,13 @@
 // axis.h -- ONE entry of cv2.resize's per-axis bilinear tables (float and double images: resize.cpp's `fx = (dx + 0.5) * scale_x - 0.5`
 // form), computed where it is needed.  Shared by the device (post.hip: the merge and the x8 upsample compute their taps and weights
-// themselves -- round 3; they used to load tables) and the host (hostplan.h builds whole tables from the same two functions, so the
-// sanitizer-tested table code and the kernels cannot drift apart).  The arithmetic is IEEE double / float multiply, subtract, floor and
+// themselves -- round 3; they used to load tables) and the host (hostplan.h includes this file and builds its whole tables --
+// plan::axis_x / axis_y -- by looping over these two functions, so the sanitizer-tested table code and the kernels cannot drift apart).  The arithmetic is IEEE double / float multiply, subtract, floor and
 // convert; post.hip is built with contraction off, so the device gets the host's bits.  HIP-free when compiled by g++.
 #pragma once
 #include <math.h>
 
 #if defined(__HIPCC__)
-#define VNECT_HD __host__ __device__ __forceinline__
+#define VNECT_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define VNECT_HD inline
 #endif

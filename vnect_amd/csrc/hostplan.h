@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 
+#include "axis.h"
 #include "tables.h"
 
 namespace vnect {
@@ -38,6 +39,8 @@ struct AxisTab {
     std::vector<float> f;
     int xmax = 0;
 };
+// Whole tables are built by looping over axis.h's single-entry functions -- the ones the kernels call (post.hip: merge, x8 upsample):
+// ONE source of this arithmetic for host tables and device code.
 // x axis: offset clamped and fraction zeroed at both borders; columns >= xmax use the single tap
 inline AxisTab axis_x(int ssize, int dsize, double scale)
 {
@@ -45,17 +48,10 @@ inline AxisTab axis_x(int ssize, int dsize, double scale)
     t.s0.resize(dsize), t.s1.resize(dsize), t.edge.resize(dsize), t.f.resize(dsize);
     t.xmax = dsize;
     for (int d = 0; d < dsize; d++) {
-        float fx = (float)((d + 0.5) * scale - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= sx;
-        if (sx < 0) fx = 0, sx = 0;
-        if (sx + 1 >= ssize) {
-            t.xmax = std::min(t.xmax, d);
-            if (sx >= ssize - 1) fx = 0, sx = ssize - 1;
-        }
-        t.s0[d] = sx, t.s1[d] = std::min(sx + 1, ssize - 1), t.f[d] = fx;
+        const vnect::AxE e = vnect::axis_x_at(d, ssize, scale);
+        t.s0[d] = e.s0, t.s1[d] = e.s1, t.edge[d] = e.edge, t.f[d] = e.f;
+        if (e.edge) t.xmax = std::min(t.xmax, d);  // the source offset is monotonic in d: edge[d] == (d >= xmax), cv2's test
     }
-    for (int d = 0; d < dsize; d++) t.edge[d] = d >= t.xmax;
     return t;
 }
 // y axis: floor + fraction kept; the two source rows are clipped into the image
@@ -64,10 +60,8 @@ inline AxisTab axis_y(int ssize, int dsize, double scale)
     AxisTab t;
     t.s0.resize(dsize), t.s1.resize(dsize), t.edge.assign(dsize, 0), t.f.resize(dsize);
     for (int d = 0; d < dsize; d++) {
-        float fy = (float)((d + 0.5) * scale - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
-        t.s0[d] = clipi(sy, 0, ssize), t.s1[d] = clipi(sy + 1, 0, ssize), t.f[d] = fy;
+        const vnect::AxE e = vnect::axis_y_at(d, ssize, scale);
+        t.s0[d] = e.s0, t.s1[d] = e.s1, t.f[d] = e.f;
     }
     return t;
 }

@@ -328,6 +328,10 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
     Filt f2, f3;
     double scaler, off;
     load_filters(fb, fp, f2, f3, scaler, off);
+    if (dyn.xfail && __hip_atomic_load(dyn.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == dyn.xseq) {
+        if (threadIdx.x == 0) out->status = 1;  // as in post_kernel: THIS frame's exchange timed out -- stale maps, the filters stay
+        return;
+    }
     joints_body<SMAX>(part, maps, geo, fb, f2, f3, scaler, off, dyn, nep50, out);
 }
 

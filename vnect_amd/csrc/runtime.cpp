@@ -1,6 +1,7 @@
 // runtime.cpp -- host side of libvnect_hip.so: handle, weight packing, launch plan, HIP graph, C ABI.
 // See include/vnect_abi.h for the boundary and the reference lines each entry point replaces.
 #include <dlfcn.h>
+#include <link.h>
 #include <unistd.h>
 #include <math.h>
 #include <stdio.h>
@@ -9,6 +10,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1104,18 +1106,56 @@ int (*p_ncclAllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nu
 int (*p_ncclCommDestroy)(void*) = nullptr;
 const char* (*p_ncclGetErrorString)(int) = nullptr;
 
+// Which copy?  A process that also runs torch.distributed's "nccl" backend (bench.py --pyramid, parallel.PyramidJob) has torch's
+// bundled torch/lib/librccl.so mapped already; /opt/rocm/lib/librccl.so.1 is ANOTHER build with the same SONAME.  Two copies in one
+// process would each keep their own bootstrap threads, proxy state and IPC caches on the same device, and with RTLD_GLOBAL the
+// second one's internal symbols could bind into the first.  So: (1) VNECT_RCCL_LIB names a file explicitly; (2) a copy this
+// process has mapped already (dl_iterate_phdr: any object whose file name starts with "librccl.so") is REUSED (RTLD_NOLOAD: a
+// reference to that very mapping); (3) only then is librccl.so.1 / librccl.so opened through the ordinary search (this library's
+// RUNPATH is the ROCm it was built with).  Always RTLD_LOCAL: only the five entry points below are looked up, by dlsym.
+std::mutex g_rccl_mu;
+bool g_rccl_reused = false;
+std::string g_rccl_path;
+int rccl_find_mapped(struct dl_phdr_info* info, size_t, void* out)
+{
+    const char* n = info->dlpi_name;
+    if (!n || !*n) return 0;
+    const char* b = strrchr(n, '/');
+    b = b ? b + 1 : n;
+    if (strncmp(b, "librccl.so", 10) != 0) return 0;
+    *(std::string*)out = n;
+    return 1;
+}
 bool load_rccl()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl) return true;
-    g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl) g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    g_rccl_reused = false;
+    const char* forced = getenv("VNECT_RCCL_LIB");
+    if (forced && *forced) {
+        g_rccl = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl) return false;  // an explicit choice that cannot be honoured is an error, not a reason to pick another copy
+    }
+    if (!g_rccl) {
+        std::string mapped;
+        dl_iterate_phdr(rccl_find_mapped, &mapped);
+        if (!mapped.empty()) g_rccl = dlopen(mapped.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (!g_rccl) g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);  // by SONAME
+        g_rccl_reused = g_rccl != nullptr;
+    }
+    if (!g_rccl) g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl) g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!g_rccl) return false;
     p_ncclGetUniqueId = (int (*)(nccl_uid*))dlsym(g_rccl, "ncclGetUniqueId");
     p_ncclCommInitRank = (int (*)(void**, int, nccl_uid, int))dlsym(g_rccl, "ncclCommInitRank");
     p_ncclAllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl, "ncclAllGather");
     p_ncclCommDestroy = (int (*)(void*))dlsym(g_rccl, "ncclCommDestroy");
     p_ncclGetErrorString = (const char* (*)(int))dlsym(g_rccl, "ncclGetErrorString");
-    if (p_ncclGetUniqueId && p_ncclCommInitRank && p_ncclAllGather && p_ncclCommDestroy) return true;
+    if (p_ncclGetUniqueId && p_ncclCommInitRank && p_ncclAllGather && p_ncclCommDestroy) {
+        Dl_info di{};  // the file the entry point really lives in (what bench.py reports)
+        g_rccl_path = dladdr((void*)p_ncclAllGather, &di) && di.dli_fname ? di.dli_fname : "?";
+        return true;
+    }
     g_rccl = nullptr;
     return false;
 }
@@ -1461,12 +1501,24 @@ int prime(vnect_handle* h)
         for (int i = 0; i < depth && !rc; i++, t += 1.0) rc = enqueue_frame(h, ps, t, t, &ring);
         for (int i = 0; i < depth && !rc; i++) rc = collect_impl(h, nullptr, nullptr);
     }
+    // A fresh handle's state comes back UNCONDITIONALLY -- the warm start is an optimisation, and the caller of vnect_finalize holds a
+    // finalized handle whatever happened to a grey frame: if one failed, whatever is still in flight is drained and dropped, the
+    // slot is emptied, the filter banks are rebuilt, and the reason is left in vnect_last_error as a note.  A device that is really
+    // broken fails the first real frame with its own error code.
+    const std::string why = rc ? h->err : std::string();
+    if (rc) {
+        (void)hipStreamSynchronize(h->st);
+        for (vnect_handle* tw : h->twins) (void)hipStreamSynchronize(tw->st);
+        (void)hipGetLastError();
+        h->seq_collect = h->seq_submit;
+    }
     h->slots[ps] = vnect_handle::SlotInfo();
-    if (!rc) rc = reset_filters_impl(h);
+    const int rf = reset_filters_impl(h);
     for (int s = 0; s < VNECT_MAX_STREAMS; s++) h->stream_seq[s] = -1, h->stream_lane[s] = nullptr;
     h->fp_dev_valid = false;  // (the next frame uploads its own geometry)
     for (vnect_handle* tw : h->twins) tw->fp_dev_valid = false;
-    return rc;
+    if (rc) h->err = "warm start skipped (not an error of vnect_finalize): " + why;
+    return rf;  // only a failure to rebuild the filter banks leaves the handle in a state a caller must not use
 }
 
 }  // namespace
@@ -2018,6 +2070,17 @@ int vnect_comm_init(vnect_handle* h, int rank, int nranks, const void* id128)
             h->comm = nullptr;
             return fail(h, VNECT_E_COMM, std::string("ncclCommInitRank: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"));
         }
+        return VNECT_OK;
+    });
+}
+
+int vnect_comm_library(char* path_out, int capacity, int32_t* reused_out)
+{
+    return guarded(nullptr, [&]() -> int {
+        if (!path_out || capacity < 2) return VNECT_E_ARG;
+        if (!load_rccl()) return fail(nullptr, VNECT_E_COMM, "librccl.so not available");
+        snprintf(path_out, (size_t)capacity, "%s", g_rccl_path.c_str());
+        if (reused_out) *reused_out = g_rccl_reused ? 1 : 0;
         return VNECT_OK;
     });
 }

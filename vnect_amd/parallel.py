@@ -17,22 +17,38 @@ def stream_seed(rank, frame, base=1234):
     return base + 1000 * rank + frame
 
 
-class Group:
-    """Thin wrapper: works with world size 1 without touching torch.distributed."""
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 
-    def __init__(self, backend="nccl"):
+
+class Group:
+    """Thin wrapper: works with world size 1 without touching torch.distributed -- unless `always_init` asks for the process group
+    anyway (a one-rank pyramid rehearsal: the same torch "nccl" == RCCL process group, all-reduce and broadcast an N-rank job runs,
+    in the same process as the library's own RCCL communicator).  `device` overrides the rank's device ordinal (one-GPU rehearsals)."""
+
+    def __init__(self, backend="nccl", always_init=False, device=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = self.local_rank if device is None else int(device)
         self.backend = backend
         self._dist = None
-        if self.world > 1:
+        if self.world > 1 or always_init:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1:
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
             kw = {}
             if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", self.local_rank)
+                have = torch.cuda.device_count()
+                if self.device >= have:   # a clean failure that names the device, instead of a HIP error out of the rendezvous
+                    raise RuntimeError("rank %d needs HIP device %d, but this machine exposes %d device(s): one rank per GPU"
+                                       % (self.rank, self.device, have))
+                kw["device_id"] = torch.device("cuda", self.device)
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self._dist = dist
 
@@ -69,7 +85,7 @@ class Group:
         kw = {}
         if self.backend == "nccl":
             import torch
-            kw["device"] = torch.device("cuda", self.local_rank)
+            kw["device"] = torch.device("cuda", self.device)
         self._dist.broadcast_object_list(box, src=src, **kw)
         return box[0]
 
