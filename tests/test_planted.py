@@ -1,0 +1,66 @@
+"""CPU: a geometric known answer for the oracle's whole path -- planted peaks through the network (tests/planted.py).
+
+The oracle's conv stack has no reference-held vectors (TF1 cannot run, no weights ship): it is cross-checked against an independent
+float64 restatement (tests/test_oracle_net.py).  This test adds something neither restatement can fake: weights built so that heat-map j
+must peak ON a blob painted into the frame, to the pixel, after the whole graph of src/vnect_model.py:27-217, the multi-scale merge
+(src/estimator.py:105-129) and extract_2d_joints (src/utils.py:153-175).  The GPU twin (fp32 and bf16, with the margin-conditioned
+bf16 gate) is tests/test_gpu_parity.py::test_bf16_margin_conditioned_joints.
+"""
+import numpy as np
+import pytest
+
+BASELINE_SCALES = [1.0, 0.8, 0.6]
+
+
+def cell_margin(up, rc):
+    """The maximum of the x8-upsampled heat-map minus its best value OUTSIDE the 8 x 8 block of pixels (one heat-map cell) that holds it."""
+    r0, c0 = (int(rc[0]) // 8) * 8, (int(rc[1]) // 8) * 8
+    rest = up.copy()
+    rest[r0:r0 + 8, c0:c0 + 8] = -np.inf
+    return float(up[int(rc[0]), int(rc[1])] - rest.max())
+
+
+@pytest.fixture(scope="module")
+def planted_net():
+    import oracle
+    from tests import planted
+    return oracle.Oracle(planted.weights())
+
+
+@pytest.mark.parametrize("seed,shape", [(1, (368, 368)), (2, (538, 368)), (3, (240, 320))])
+def test_oracle_finds_the_planted_joints(planted_net, seed, shape):
+    import oracle
+    from tests import planted
+    H, W = shape
+    frame, centres = planted.frame(seed, H, W)
+    want = planted.expected(centres)
+    est = oracle.OracleEstimator(scales=BASELINE_SCALES, net=planted_net)
+    j2, j3 = est(frame, 1.0, 1.0)                       # first frame of a stream: the filters are the identity
+    scaler = 368.0 / max(H, W)
+    assert np.abs(j2 - want).max() <= 1.0 / scaler, (np.abs(j2 - want).max(), scaler)    # ON the blob: within one box pixel
+    assert np.all(np.isfinite(j3))
+    # and these are REAL maxima: most of them clear every other cell by more than 2 eps, eps = 3e-2 * max|maps| (the bf16 map gate)
+    batch, _, _ = oracle.gen_input_batch(frame, BASELINE_SCALES)
+    maps = planted_net.forward(batch)
+    eps = 3e-2 * float(np.abs(maps).max())
+    avg = oracle.merge_scales(maps, BASELINE_SCALES)[0]
+    raw = oracle.extract_2d(avg)
+    m = [cell_margin(oracle.resize(np.ascontiguousarray(avg[:, :, j]), 8.0), raw[j]) / eps for j in range(21)]
+    assert sum(x > 2.0 for x in m) >= 12, m
+
+
+def test_planted_weights_keep_the_schema_and_isolate_the_pass_channels():
+    from tests import planted
+    from vnect_amd.weights import check_schema, synthetic_weights
+    w, base = planted.weights(), synthetic_weights()
+    check_schema(w)
+    for name, a in w.items():
+        scope, leaf = name.split("/")
+        if leaf == "weights" and scope not in ("conv1", "res5c_branch2b"):   # (res5c_branch2b fans the 3 colours out to 21 joint channels)
+            # no random output reads a pass channel, no pass output reads a random channel
+            assert not np.any(a[:, :, :planted.P, planted.P:]) and not np.any(a[:, :, planted.P:, :planted.P]), name
+    k = w["res5c_branch2b/weights"]
+    assert not np.any(k[:, :, planted.P:, :21]) and not np.any(k[:, :, :planted.P, 21:]) and np.count_nonzero(k[:, :, :planted.P, :21]) == 21
+    # the random part is the seeded synthetic net
+    k, b = w["res4c_branch2b/weights"], base["res4c_branch2b/weights"]
+    assert np.array_equal(k[:, :, planted.P:, planted.P:], b[:, :, planted.P:, planted.P:])
