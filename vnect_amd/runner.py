@@ -35,17 +35,17 @@ def run_pic(estimator, img, rect=None, timestamp=None):
 
 
 def bbox_update(joints_2d, W_img, H_img):
-    """run_estimator_ps.py:96-107: next crop rectangle (x, y, w, h) from the 2-D joints in frame coordinates."""
-    y_min = np.min(joints_2d[:, 0])
-    y_max = np.max(joints_2d[:, 0])
-    x_min = np.min(joints_2d[:, 1])
-    x_max = np.max(joints_2d[:, 1])
-    buffer_x = 0.8 * (x_max - x_min + 1)
-    buffer_y = 0.2 * (y_max - y_min + 1)
-    x, y = (max(int(x_min - buffer_x / 2), 0),
-            max(int(y_min - buffer_y / 2), 0))
-    w, h = (int(min(x_max - x_min + buffer_x, W_img - x)),
-            int(min(y_max - y_min + buffer_y, H_img - y)))
+    """The tracking loop's next crop rectangle (x, y, w, h) from the 2-D joints in frame coordinates -- the rule of
+    run_estimator_ps.py:96-107: the joints' bounding box grown by 80 % of (its width + 1) and 20 % of (its height + 1), half of the
+    margin before the box, the whole margin added to its extent, clamped to the frame; integer truncation as there."""
+    lo = joints_2d.min(axis=0)                 # [row, col] = [y, x]
+    span = joints_2d.max(axis=0) - lo
+    rect = {}
+    for axis, grow, limit in ((1, 0.8, W_img), (0, 0.2, H_img)):
+        margin = grow * (span[axis] + 1)
+        origin = max(int(lo[axis] - margin / 2), 0)
+        rect[axis] = (origin, int(min(span[axis] + margin, limit - origin)))
+    (x, w), (y, h) = rect[1], rect[0]
     return [x, y, w, h]
 
 
