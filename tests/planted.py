@@ -116,3 +116,18 @@ def expected(centres):
     """joints_2d ([row, col] in frame pixels) the planted weights must produce for a frame from frame(): joint j sits on the bright blob
     of colour j % 3."""
     return np.array([centres[j % 3] for j in range(21)], np.float64)
+
+
+def scene(H, W, blobs, sigma, seed=0, texture=0.15):
+    """uint8 BGR frame (H, W, 3): the dim texture of frame() with Gaussian blobs `blobs` = [(row, col, colour 0..2, amplitude 0..255)] of
+    width `sigma` (frame pixels) anywhere -- the tracking loop's crops do not keep a blob on the lattice of frame(), so peaks through a
+    crop are broader and the known answer is "within a heat-map cell or two of the blob", not "to the pixel"."""
+    g = uniform01(seed + 77, 9 * 9 * 3).reshape(9, 9, 3).astype(np.float64)
+    ys, xs = np.linspace(0, 8, H, endpoint=False), np.linspace(0, 8, W, endpoint=False)
+    y0, x0 = ys.astype(int), xs.astype(int)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    img = ((g[y0][:, x0] * (1 - fx) + g[y0][:, x0 + 1] * fx) * (1 - fy) + (g[y0 + 1][:, x0] * (1 - fx) + g[y0 + 1][:, x0 + 1] * fx) * fy) * 255.0 * texture
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    for r, c, k, amp in blobs:
+        img[:, :, k] += amp * np.exp(-((yy - r) ** 2 + (xx - c) ** 2) / (2.0 * sigma * sigma))
+    return np.clip(img, 0, 255).astype(np.uint8)

@@ -728,6 +728,49 @@ def test_tracking_loop_variable_crops(weights, oracle_net):
     est.close()
 
 
+def test_tracking_loop_follows_planted_blobs():
+    """The tracking loop with a KNOWN answer on the GPU (tests/planted.py; CPU twin with the oracle: tests/test_planted.py): a 640 x 480 video of
+    three drifting blobs through runner.track (run_estimator_ps.py:80-109) -- whole frame first, then crops by the box rule, every crop a
+    different size, squarified and resized on the device.  fp32: the loop is the ORACLE's loop joint for joint (joints_2d array_equal in every
+    frame -- planted peaks leave no ties --, hence the same crops; joints_3d within the fp32 tolerance); fp32 and bf16: every joint within two
+    heat-map cells of its blob, every crop within 2.5 cells + 8 pixels of the box rule applied to the true positions."""
+    import oracle
+    from tests import planted
+    from tests.test_planted import moving_person
+    from vnect_amd import VNectEstimator, runner
+    H, W, n = 480, 640, 8
+    pw = planted.weights()
+    net = oracle.Oracle(pw)
+    frames = [planted.scene(H, W, moving_person(k), sigma=10.0, seed=k) for k in range(n)]
+    stamps = [T0 + 50 + i / 30 for i in range(n)]
+
+    class OracleEst:
+        def __init__(self):
+            self.o = oracle.OracleEstimator(scales=BASELINE_SCALES, net=net)
+
+        def __call__(self, img, timestamp=None):
+            return self.o(np.ascontiguousarray(img), timestamp, timestamp)
+
+    ref = list(runner.track(OracleEst(), frames, timestamps=stamps))
+    for prec in ("fp32", "bf16"):
+        est = VNectEstimator(scales=BASELINE_SCALES, weights=pw, precision=prec, verbose=False)
+        prev_ideal, worst = None, 0.0
+        for k, (j2, j3, rect) in enumerate(runner.track(est, frames, timestamps=stamps)):
+            want = np.array([moving_person(k)[j % 3][:2] for j in range(21)], np.float64)
+            cell = 8.0 / (368.0 / max(rect[2], rect[3]))
+            worst = max(worst, float(np.abs(j2 - want).max()) / cell)
+            assert np.abs(j2 - want).max() <= max(2.0 * cell, 14.0), (prec, k, rect, float(np.abs(j2 - want).max()))
+            if prev_ideal is not None:
+                assert np.abs(np.array(rect) - np.array(prev_ideal)).max() <= 2.5 * prev_cell + 8, (prec, k, rect, prev_ideal)
+            prev_ideal, prev_cell = runner.bbox_update(want, W, H), cell
+            if prec == "fp32":
+                r2, r3, rrect = ref[k]
+                assert rect == rrect and np.array_equal(j2, r2), (k, rect, rrect)
+                assert np.all(np.abs(j3 - r3) <= 0.05 + 1e-4 * np.abs(r3)), k
+        print("%s: tracked %d frames, joints at most %.2f heat-map cells from their blobs" % (prec, n, worst))
+        est.close()
+
+
 # ------------------------------------------------------------------------------------------ pyramid sharding
 def test_pyramid_shards_reassemble(weights, oracle_net):
     """configs[3] without a second GPU: three rank-handles (one scale each) run their own pre-processing and conv

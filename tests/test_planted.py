@@ -64,3 +64,39 @@ def test_planted_weights_keep_the_schema_and_isolate_the_pass_channels():
     # the random part is the seeded synthetic net
     k, b = w["res4c_branch2b/weights"], base["res4c_branch2b/weights"]
     assert np.array_equal(k[:, :, planted.P:, planted.P:], b[:, :, planted.P:, planted.P:])
+
+
+def moving_person(k):
+    """three blobs (colour 0, 1, 2: the 'person' every joint j sits on by j % 3) drifting right and down by (5, 2) pixels per frame"""
+    return [(150 + 2 * k, 250 + 5 * k, 0, 255), (300 + 2 * k, 300 + 5 * k, 1, 255), (330 + 2 * k, 220 + 5 * k, 2, 255)]
+
+
+def test_tracking_loop_locks_onto_the_planted_person(planted_net):
+    """The caller loop of run_estimator_ps.py:80-109 (vnect_amd.runner.track) with a known answer: a 640 x 480 video of three drifting blobs.
+    From the whole frame the loop must find them, crop around them by the box rule (:96-107) and follow them: every joint within two
+    heat-map cells of its blob in every frame, every crop within 2.5 cells (of the crop it was measured in) + 8 pixels of the box rule applied to the true positions.  (The oracle
+    behind the estimator surface; the GPU twin -- fp32 equal to this loop joint for joint, and bf16 -- is
+    tests/test_gpu_parity.py::test_tracking_loop_follows_planted_blobs.)"""
+    import oracle
+    from tests import planted
+    from vnect_amd import runner
+    H, W, n = 480, 640, 5
+
+    class OracleEst:
+        def __init__(self):
+            self.o = oracle.OracleEstimator(scales=BASELINE_SCALES, net=planted_net)
+
+        def __call__(self, img, timestamp=None):
+            return self.o(np.ascontiguousarray(img), timestamp, timestamp)
+
+    frames = [planted.scene(H, W, moving_person(k), sigma=10.0, seed=k) for k in range(n)]
+    prev_ideal = None
+    for k, (j2, j3, rect) in enumerate(runner.track(OracleEst(), frames, timestamps=[10 + i / 30 for i in range(n)])):
+        want = np.array([moving_person(k)[j % 3][:2] for j in range(21)], np.float64)
+        cell = 8.0 / (368.0 / max(rect[2], rect[3]))                      # one heat-map cell in frame pixels for this crop
+        assert np.abs(j2 - want).max() <= max(2.0 * cell, 14.0), (k, rect, float(np.abs(j2 - want).max()))
+        if prev_ideal is not None:    # (a joint error of e pixels moves a box edge by up to 1.8 e: the rule adds 80 % of the width)
+            assert np.abs(np.array(rect) - np.array(prev_ideal)).max() <= 2.5 * prev_cell + 8, (k, rect, prev_ideal)
+        else:
+            assert rect == [0, 0, W, H]
+        prev_ideal, prev_cell = runner.bbox_update(want, W, H), cell
