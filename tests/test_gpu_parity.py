@@ -258,6 +258,48 @@ def test_fused_stem_fuzz_frame_shapes_and_scales(weights, monkeypatch):
         fused.close(), ref.close()
 
 
+def test_deconv_three_accumulator_shape(weights, oracle_net, monkeypatch):
+    """The transposed convs res5c_branch1a / res5c_branch2a (+ BN + ReLU; vnect_model.py:188-196) on 64 x 96 tiles with two K groups and THREE
+    accumulators per wave (conv.hip: NACC; round 4: 200 tiles in one round instead of 300 in two) -- the fp32 plan at three scales.  Plain
+    (per-layer read-back) and with the bone features in its launch (arena plan): res5c_branch2a_feat within 1e-4 of the oracle, the two forms
+    bit-identical, the 64 x 64 plan (VNECT_NO_DECONV96=1) equal to fp32 rounding (another summation order: two K groups), final maps alike;
+    bf16, four scales and a split-product handle keep the 64 x 64 tiles."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
+    ref = oracle_net.forward(batch)
+    feat_ref = oracle_net.activation("res5c_branch2a_feat")
+    top = float(np.abs(feat_ref).max())
+
+    def tile_of(h):
+        L = [x for x in h.layers() if x["name"].startswith("res5c_deconv")]
+        assert len(L) == 1
+        return (L[0]["tile_m"], L[0]["tile_n"], L[0]["workgroups"], L[0]["name"])
+
+    keep = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    arena = _handle(BASELINE_SCALES, weights)
+    assert tile_of(keep)[:3] == (64, 96, 200) and tile_of(arena) == (64, 96, 200, "res5c_deconv+bone_length"), (tile_of(keep), tile_of(arena))
+    mk, ma = keep.forward(batch), arena.forward(batch)
+    fk = keep.activation("res5c_branch2a_feat")
+    assert fk.shape == feat_ref.shape and float(np.abs(fk - feat_ref).max()) <= 1e-4 * top
+    assert np.array_equal(mk, ma)                                  # bone features inside the launch == the stand-alone bone kernel
+    assert float(np.abs(ma - ref).max()) <= 1e-4 * float(np.abs(ref).max())
+    monkeypatch.setenv("VNECT_NO_DECONV96", "1")
+    old = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    monkeypatch.delenv("VNECT_NO_DECONV96")
+    assert tile_of(old)[:3] == (64, 64, 300)
+    mo = old.forward(batch)
+    fo = old.activation("res5c_branch2a_feat")
+    assert float(np.abs(fo - fk).max()) <= 2e-5 * top and float(np.abs(mo - mk).max()) <= 2e-5 * float(np.abs(ref).max())
+    for h in (keep, arena, old):
+        h.close()
+    for kw, scales in ((dict(precision=n.BF16), BASELINE_SCALES), (dict(precision=n.FP32_SPLIT), BASELINE_SCALES), (dict(), [1.0, 0.9, 0.8, 0.7])):
+        h = _handle(scales, weights, **kw)
+        assert tile_of(h)[:2] == (64, 64), (kw, scales, tile_of(h))
+        h.close()
+
+
 def test_conv_stack_batch_independent(h3, oracle_net):
     """The S images are independent: permuting the batch permutes the output (what sharding relies on)."""
     import oracle

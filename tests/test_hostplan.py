@@ -46,6 +46,7 @@ def hp():
     L.hp_arena.argtypes = [i32p, i32p, u64p, C.c_int, u64p]
     L.hp_arena.restype = C.c_uint64
     L.hp_choose_tile.argtypes = [C.c_int] * 7 + [C.c_char_p] * 3 + [i32p]
+    L.hp_choose_tile96.argtypes = [C.c_int] * 7 + [C.c_char_p] * 3 + [i32p]
     L.hp_stem_groups.argtypes = [C.c_int, u8p]
     L.hp_stem_frame_fits.argtypes = [f64p, C.c_int, C.c_int, C.c_int]
     return L
@@ -322,6 +323,17 @@ def test_tile_choice_invariants_over_the_whole_network(hp):
     hp.hp_choose_tile(1587, 256, 9, 8, 2304, 1, 0, b"res4b_branch2b", None, b"res4a_branch2b=64,64,1,2;res4b_branch2b=32,32,4,3", out)
     assert list(out) == [32, 32, 4, 3]
     hp.hp_choose_tile(1587, 256, 9, 8, 2304, 1, 0, b"branch2b", None, b"res4b_branch2b=32,32,4,3", out)   # a suffix is not a match
+    assert list(out) == [64, 32, 2, 1]
+    # the transposed conv (4 phases, N = 191, K = 4 taps x 256): 300 tiles of 64x64 at three scales -> the three-accumulator 64x96x2 shape
+    # (200 tiles) where it is allowed, fp32 only, and only while it saves a round (one scale takes the 64x32x2 K groups as before, two scales fit one round of 64x64 tiles; four
+    # scales need two rounds either way)
+    dc = lambda fn, M, bf16=0, force=None, plan=None: (fn(M, 191, 4, 8 if not bf16 else 4, 1024, 4, bf16, b"res5c_deconv", force, plan, out), list(out))[1]
+    assert dc(hp.hp_choose_tile96, 3 * 529) == [64, 96, 2, 1] and dc(hp.hp_choose_tile, 3 * 529) == [64, 64, 1, 1]
+    assert dc(hp.hp_choose_tile96, 3 * 529, bf16=1) == [64, 64, 1, 1]
+    assert dc(hp.hp_choose_tile96, 529) == [64, 32, 2, 1] and dc(hp.hp_choose_tile96, 2 * 529) == [64, 64, 1, 1] and dc(hp.hp_choose_tile96, 4 * 529) == [64, 64, 1, 1]
+    assert dc(hp.hp_choose_tile, 3 * 529, plan=b"res5c_deconv=64,96,2,1") == [64, 96, 2, 1]           # by plan, on the layer it is built for
+    assert dc(hp.hp_choose_tile96, 3 * 529, plan=b"res5c_deconv=64,64,1,1") == [64, 64, 1, 1]
+    hp.hp_choose_tile(1587, 256, 9, 8, 2304, 1, 0, b"res4b_branch2b", b"64,96,2,1", None, out)                 # ... and on no other
     assert list(out) == [64, 32, 2, 1]
 
 

@@ -34,7 +34,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void wait_vm()
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    // (the counter has six bits; a larger count can only be asked for by a branch no ring of that shape ever takes, and the stricter wait is safe)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
 }
 
 // x / d for 0 <= x, x * d < 2^32, with mg = ceil(2^32 / d) (d == 1: mg wraps to 0, handled); one v_mul_hi instead of
@@ -554,20 +555,27 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
 {
     constexpr bool TAIL = FUSE == 1 || FUSE == 3, BONE = FUSE == 2, CHAIN = FUSE == 3;  // 3: the wide tail with a chain GEMM behind it
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
+    // NACC (round 4): 32-column blocks per consumer wave.  64 x 96 x 2 -- two K groups x two row blocks, every wave THREE accumulators that share
+    // its A fragments -- exists for the transposed conv in fp32: 300 tiles of 64 x 64 on 256 CUs are two rounds for 44 of them, 200 tiles
+    // of 64 x 96 one round of 1.5 block-K-loops per SIMD (vnect_model.py:188-196).
+    constexpr int NACC = BN == 96 ? 3 : 1;
+    static_assert(NACC == 1 || (BM == 64 && KG == 2 && !BF && !X3 && !SPAN && (FUSE == 0 || FUSE == 2)), "the three-accumulator shape is fp32, plain or with the bone features");
     static_assert(!X3 || (BM == 64 && (BN * KG == 64) && !BF && !SPAN && PROF < 2), "split-product form: 64x64 and 64x32x2 tiles of fp32 layers");
-    static_assert(FUSE == 0 || ((FUSE != 3 || (BF && !X3)) && BM == 64 && BN == 64 && KG == 1) || ((FUSE == 1 || FUSE == 3) && BM == 32 && BN == 128 && KG == 1),
+    static_assert(FUSE == 0 || ((FUSE != 3 || (BF && !X3)) && BM == 64 && BN == 64 && KG == 1) || ((FUSE == 1 || FUSE == 3) && BM == 32 && BN == 128 && KG == 1) ||
+                      (FUSE == 2 && BM == 64 && BN == 96 && KG == 2),
                   "the fused forms are built for one 64x64 tile per workgroup; the tail GEMM also for one 32x128 tile (tail_wide)");
     constexpr bool WIDE = BN == 128;
     constexpr int ESZ = BF ? 2 : 4;    // bytes per operand element
     constexpr int EPR = BF ? 64 : 32;  // K-elements per 128-B row (= per chunk)
     constexpr int EPU = BF ? 8 : 4;    // elements per 16-B unit
-    constexpr int ARB = BM / 32, BRB = BN / 32, WMN = ARB * BRB;  // 32-row blocks of A and B; accumulators per K group
+    constexpr int ARB = BM / 32, BRB = BN / 32, WNW = BRB / NACC, WMN = ARB * WNW;  // 32-row blocks of A and B; consumer waves over N; consumer waves per K group
     constexpr int BROWF = X3 ? 48 : 32;                          // floats per B row and chunk (X3: three 64-byte planes, plane-major in the stage)
     constexpr int ROWS = BM + BN, SUB = BM * 32 + BN * BROWF;    // one K group's image: BM A rows x 128 B, then the B rows
     constexpr int STAGE = SUB * KG, NLD = SPAN ? 1 + BRB : (X3 ? KG * ARB + 3 : KG * ROWS / 32);  // floats per ring stage; LDS-DMA instructions per producer wave per step
-    constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x 4 KiB, then WMN*(KG-1) flags
+    constexpr int SCRATCH = NS * STAGE;                          // K-group partial sums: (KG-1) x WMN x NACC x 4 KiB, then WMN*(KG-1) flags
+    constexpr int NPART = (KG - 1) * WMN * NACC;                  // 4-KiB partial accumulators behind the ring
     constexpr bool P1 = PROF >= 1, P2 = PROF >= 2;
-    static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64 || BN == 128), "four consumer waves, one 32x32 accumulator each");
+    static_assert(WMN * KG == 4 && (BM == 32 || BM == 64) && (BN == 32 || BN == 64 || BN == 96 || BN == 128), "four consumer waves, NACC 32x32 accumulators each");
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {   // The 344-byte argument block spans six scalar-cache lines and the compiler loads fields where they are first
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     unsigned long long* const prof = a.prof;  // not pinned: stays a global-address-space pointer
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
-    const int kg = wave / WMN, wr = wave % WMN, wm = wr / BRB, wn = wr % BRB;  // consumers: K group, tile row / column block
+    const int kg = wave / WMN, wr = wave % WMN, wm = wr / WNW, wn = (wr % WNW) * NACC;  // consumers: K group, tile row block / first column block
     // start stamp: workgroup 0 (first dispatched; a grid starts first -> last within ~0.5 us).  Plain store: nothing in the
     // twin may queue behind an atomic.
     if (P1 && threadIdx.x == 0 && blockIdx.x == 0) prof[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
@@ -878,7 +886,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         }
         if constexpr (BONE) {
             const Item it0 = decode(0);
-            if (it0.n0 == BONE_N0) {  // the tile that holds the 63 delta columns (uniform per workgroup)
+            if (it0.n0 <= BONE_N0 && it0.n0 + BN > BONE_N0) {  // the tile that holds the 63 delta columns (uniform per workgroup)
                 __builtin_amdgcn_s_barrier();  // ... is in LDS now
                 bone_features<BF>(a, smem, it0.m0, it0.phase, tid, h.M, h.Wo, h.Ho, h.mg_wo, h.mg_ho);
             }
@@ -903,15 +911,23 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     };
     struct Frag {
         f32x4 a[4], b[4];
+        f32x4 bx[NACC > 1 ? NACC - 1 : 1][4];  // NACC > 1: the B fragments of the wave's column blocks 1 .. NACC - 1
     };
     Frag F0, F1;
     f32x16 acc;
+    f32x16 accx[NACC > 1 ? NACC - 1 : 1];  // NACC > 1: the accumulators of column blocks 1 .. NACC - 1 (block 0 is `acc`)
     WideRegs<BF> TWc;  // (the wide tail's operands of this consumer wave)
     auto rall = [&](int stg, Frag& F) __attribute__((always_inline)) {
         const float* Ab = smem + stg * STAGE + kg * SUB + (SPAN ? 0 : (wm * 32) * 32);
         const float* Bb = smem + stg * STAGE + kg * SUB + (BM + wn * 32) * 32;
 #pragma unroll
         for (int q = 0; q < 4; q++) F.a[q] = *(const f32x4*)(Ab + (SPAN ? foA[q] : fo[q])), F.b[q] = *(const f32x4*)(Bb + fo[q]);
+        if constexpr (NACC > 1) {
+#pragma unroll
+            for (int b = 1; b < NACC; b++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) F.bx[b - 1][q] = *(const f32x4*)(Bb + b * 1024 + fo[q]);
+        }
     };
     auto mma = [&](const f32x4& af, const f32x4& bf) __attribute__((always_inline)) {
         if constexpr (BF) {
@@ -953,6 +969,27 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                         nxt.b[q] = *(const f32x4*)(Bb + fo[q]);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+        } else if constexpr (!BF && NACC > 1) {
+            // NACC accumulators per wave: every A value feeds NACC MFMAs (independent chains, so the pipe never waits on a dependency);
+            // the next chunk's 4 + 4 NACC fragment reads go out one per MFMA group
+            const float* Ab = smem + nstage * STAGE + kg * SUB + (wm * 32) * 32;
+            const float* Bb = smem + nstage * STAGE + kg * SUB + (BM + wn * 32) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], cur.b[q][e], acc, 0, 0, 0);
+#pragma unroll
+                    for (int b = 1; b < NACC; b++) accx[b - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], cur.bx[b - 1][q][e], accx[b - 1], 0, 0, 0);
+                    const int r = q * 4 + e;  // 0..15: A fragments 0..3, then the B fragments of blocks 0 .. NACC - 1
+                    if (r < 4) nxt.a[r] = *(const f32x4*)(Ab + fo[r]);
+                    else if (r < 8) nxt.b[r - 4] = *(const f32x4*)(Bb + fo[r - 4]);
+                    else if (r - 8 < 4 * (NACC - 1)) nxt.bx[(r - 8) >> 2][(r - 8) & 3] = *(const f32x4*)(Bb + (((r - 8) >> 2) + 1) * 1024 + fo[(r - 8) & 3]);
+                    if (r < 4 + 4 * NACC) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);  // NACC MFMAs ...
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // ... then one DS read
                     }
                 }
         } else if constexpr (!BF) {
@@ -1102,7 +1139,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     cgfloat* resid = fused && !TAIL ? (cgfloat*)c.resid : nullptr;  // (a tail layer's shortcut belongs to its second GEMM)
     if (pstamp) prof[10] = __builtin_amdgcn_s_memrealtime();
     if constexpr (KG > 1) {
-        if (threadIdx.x < (KG - 1) * WMN) ((volatile int*)(smem + SCRATCH + (KG - 1) * WMN * 1024))[threadIdx.x] = 0;
+        if (threadIdx.x < (KG - 1) * WMN) ((volatile int*)(smem + SCRATCH + NPART * 1024))[threadIdx.x] = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // chunk 0 visible
@@ -1133,9 +1170,17 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         if constexpr (TAIL && WIDE) wide_load_resid<BF>(a, it.m0, 4 + wave, lane, TWc);  // the tail's shortcut values: requested before the K loop
         unsigned rsw[16];  // shortcut values as loaded (fp32 bits, or a zero-extended bf16): converting a bf16 here would make
                            // the compiler wait for the loads BEFORE the K loop (measured: 15 us per 92x92 shortcut layer)
+        float biasx[NACC > 1 ? NACC - 1 : 1] = {}, scx[NACC > 1 ? NACC - 1 : 1] = {}, shx[NACC > 1 ? NACC - 1 : 1] = {};  // column blocks 1 .. NACC - 1
         if (fused && kg == 0) {
             bias = ((cgfloat*)c.bias)[n];
             if (c.scale) sc = ((cgfloat*)c.scale)[n], sh = ((cgfloat*)c.shift)[n];
+            if constexpr (NACC > 1) {
+#pragma unroll
+                for (int b = 1; b < NACC; b++) {
+                    biasx[b - 1] = ((cgfloat*)c.bias)[n + 32 * b], scx[b - 1] = 1.f;
+                    if (c.scale) scx[b - 1] = ((cgfloat*)c.scale)[n + 32 * b], shx[b - 1] = ((cgfloat*)c.shift)[n + 32 * b];
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) rsw[r] = 0u;
@@ -1159,6 +1204,12 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        if constexpr (NACC > 1) {
+#pragma unroll
+            for (int b = 1; b < NACC; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) accx[b - 1][r] = 0.f;
+        }
         if constexpr (X3) {
             for (int t = 0; t < it.cnt; t++) step3();
         } else {
@@ -1175,34 +1226,64 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
             // reset; a partial is not overwritten early because the writer first has to pass the next item's K-loop
             // barriers, which group 0 joins only after this epilogue.
             float* part = smem + SCRATCH;
-            volatile int* flags = (volatile int*)(smem + SCRATCH + (KG - 1) * WMN * 1024);
+            volatile int* flags = (volatile int*)(smem + SCRATCH + NPART * 1024);
             if (kg > 0) {
-                float* dst = part + ((kg - 1) * WMN + wr) * 1024 + lane * 4;
+                float* dst = part + ((kg - 1) * WMN + wr) * NACC * 1024 + lane * 4;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) *(f32x4*)(dst + r4 * 256) = f32x4{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                if constexpr (NACC > 1) {
+#pragma unroll
+                    for (int b = 1; b < NACC; b++)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++)
+                            *(f32x4*)(dst + b * 1024 + r4 * 256) = f32x4{accx[b - 1][4 * r4], accx[b - 1][4 * r4 + 1], accx[b - 1][4 * r4 + 2], accx[b - 1][4 * r4 + 3]};
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) flags[(kg - 1) * WMN + wr] = j + 1;
+                if constexpr (BONE) {  // (every wave of the workgroup meets at the bone stage's barrier, the K groups that hand their sums over too)
+                    if (it.n0 <= BONE_N0 && it.n0 + BN > BONE_N0) __builtin_amdgcn_s_barrier();
+                }
                 continue;
             }
 #pragma unroll
             for (int k = 1; k < KG; k++) {
                 while (flags[(k - 1) * WMN + wr] != j + 1) __builtin_amdgcn_s_sleep(1);
-                const float* src = part + ((k - 1) * WMN + wr) * 1024 + lane * 4;
+                const float* src = part + ((k - 1) * WMN + wr) * NACC * 1024 + lane * 4;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) {
                     const f32x4 v = *(const f32x4*)(src + r4 * 256);
                     acc[4 * r4] += v[0], acc[4 * r4 + 1] += v[1], acc[4 * r4 + 2] += v[2], acc[4 * r4 + 3] += v[3];
                 }
+                if constexpr (NACC > 1) {
+#pragma unroll
+                    for (int b = 1; b < NACC; b++)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const f32x4 v = *(const f32x4*)(src + b * 1024 + r4 * 256);
+                            accx[b - 1][4 * r4] += v[0], accx[b - 1][4 * r4 + 1] += v[1], accx[b - 1][4 * r4 + 2] += v[2], accx[b - 1][4 * r4 + 3] += v[3];
+                        }
+                }
             }
         }
 
         if constexpr (BONE) {
-            if (it.n0 == BONE_N0) {
+            if (it.n0 <= BONE_N0 && it.n0 + BN > BONE_N0) {
                 // the 63 delta columns of this row block (no bias, no BN on these columns: the accumulators ARE the values the
                 // epilogue below stores) go to LDS for the producer waves, which have nothing left to do and compute the
                 // bone lengths from them while this wave runs its ordinary epilogue
+                if constexpr (NACC == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) smem[(wm * 32 + rhalf + (r & 3) + 8 * (r >> 2)) * BONE_LS + wn * 32 + col] = acc[r];
+                    for (int r = 0; r < 16; r++) smem[(wm * 32 + rhalf + (r & 3) + 8 * (r >> 2)) * BONE_LS + wn * 32 + col] = acc[r];
+                } else {  // the 96-wide tile 96 .. 191: its column blocks 1 and 2 are the delta columns 128 .. 191
+#pragma unroll
+                    for (int b = 1; b < NACC; b++) {
+                        const int c0 = it.n0 + (wn + b) * 32 - BONE_N0;  // >= 0 for the blocks that hold delta columns (uniform)
+                        if (c0 >= 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) smem[(wm * 32 + rhalf + (r & 3) + 8 * (r >> 2)) * BONE_LS + c0 + col] = accx[b - 1][r];
+                        }
+                    }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -1250,6 +1331,37 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                 }
             }
             break;  // one tile per workgroup: nothing of the K-loop state (prefetched fragments, item bookkeeping) lives on
+        }
+        if constexpr (NACC > 1) {
+            // ---- epilogue of the NACC-accumulator shape (fp32; no shortcut, one output tensor, no K slabs: launch_stream checks) ----
+            // One pass over the lane's 16 rows: a row's output pixel -- two multiply-high divisions for the transposed conv's scatter
+            // to (2 i + py, 2 j + px) -- is computed ONCE and serves the row's NACC stores (columns n, n + 32, ...).
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias), "+v"(sc), "+v"(sh), "+v"(biasx[0]), "+v"(scx[0]), "+v"(shx[0]), "+v"(biasx[NACC - 2]), "+v"(scx[NACC - 2]), "+v"(shx[NACC - 2]));
+            const int py = it.phase >> 1, px = it.phase & 1;
+            gfloat* const outp = (gfloat*)c.out;
+            bool relub[NACC];
+#pragma unroll
+            for (int b = 0; b < NACC; b++) relub[b] = it.n0 + (wn + b) * 32 < c.relu_cols;  // uniform per block: relu_cols is a multiple of 32
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                int opix = m;
+                if (!direct) {
+                    const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
+                    const int sI = fdiv(t, h.mg_ho, h.Ho), oy = t - sI * h.Ho;
+                    opix = (sI * c.OH + oy * c.os + py) * c.OW + ox * c.os + px;
+                }
+                const unsigned off = (unsigned)(opix * c.ldc + n);
+#pragma unroll
+                for (int b = 0; b < NACC; b++) {
+                    float o = (b == 0 ? acc[r] : accx[b > 0 ? b - 1 : 0][r]) + (b == 0 ? bias : biasx[b > 0 ? b - 1 : 0]);
+                    if (c.scale) o = o * (b == 0 ? sc : scx[b > 0 ? b - 1 : 0]) + (b == 0 ? sh : shx[b > 0 ? b - 1 : 0]);
+                    if (relub[b]) o = __builtin_fmaxf(o, 0.f);
+                    if (m < h.M && n + 32 * b < c.Nvalid) put_f32(outp + off + 32 * b, o);
+                }
+            }
+            if (pstamp && j == 0) prof[21] = __builtin_amdgcn_s_memrealtime();
+            continue;
         }
         // epilogue from registers.  One explicit wait for the bias / shortcut values requested before the K loop, with
         // the values passed through it: otherwise the compiler re-waits (vmcnt(0)) for those loads before every use,
@@ -1359,7 +1471,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 }
 
 template <int BM, int BN, int KG, int NS>
-constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
+constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * (BN == 96 ? 3 : 1) * 4096 + 64 : 0); }
 // split-product form: a stage holds BM x 128 B of activations and BN x 192 B of weight planes per K group
 template <int BM, int BN, int KG, int NS>
 constexpr size_t x3_stream_lds() { return (size_t)NS * (BM * 32 + BN * 48) * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
@@ -1440,6 +1552,21 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
             return hipGetLastError();
         }
     }
+    if constexpr (BN == 96) {
+        // three accumulators per wave (fp32): no shortcut, one output tensor, no K slabs, no tail; plain or with the bone features
+        if (a.bf16 || a.x3 || a.tail_n > 0 || a.resid || a.out2 || a.ksplit != 1 || a.pixmode || (a.relu_cols & 31)) return hipErrorInvalidValue;
+        if (a.bone && (a.items > maxwg || a.Npad != 192 || a.ldc < 212)) return hipErrorInvalidValue;
+#define LAUNCH_96(PR, FU) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, false, PR, FU>), grid, dim3(512), lds, st, a)
+        if (a.bone) {
+            if (prof == 0) LAUNCH_96(0, 2);
+            else LAUNCH_96(1, 2);
+        } else {
+            if (prof == 0) LAUNCH_96(0, 0);
+            else LAUNCH_96(1, 0);
+        }
+#undef LAUNCH_96
+        return hipGetLastError();
+    }
     if constexpr (BM == 32 && BN == 128 && KG == 1) {
         if (a.tail_n > 0) {  // the wide tail (tail_wide): one 32x128 tile per workgroup, K = 128, at most 16 column blocks
             if (a.x3 || a.bone || a.items > maxwg || a.ksplit != 1 || a.nphase != 1 || a.Npad != 128 || a.os != 1 || a.tail_n > 512 || !a.tail_w || !a.tail_bias ||
@@ -1489,21 +1616,43 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
             return hipGetLastError();
         }
     }
-    if (a.bf16) {
-        if (prof == 0) LAUNCH_STREAM(true, 0);
-        else if (prof == 1) LAUNCH_STREAM(true, 1);
-        else LAUNCH_STREAM(true, 2);
-    } else {
-        if (prof == 0) LAUNCH_STREAM(false, 0);
-        else if (prof == 1) LAUNCH_STREAM(false, 1);
-        else LAUNCH_STREAM(false, 2);
+    if constexpr (BN != 96) {
+        if (a.bf16) {
+            if (prof == 0) LAUNCH_STREAM(true, 0);
+            else if (prof == 1) LAUNCH_STREAM(true, 1);
+            else LAUNCH_STREAM(true, 2);
+        } else {
+            if (prof == 0) LAUNCH_STREAM(false, 0);
+            else if (prof == 1) LAUNCH_STREAM(false, 1);
+            else LAUNCH_STREAM(false, 2);
+        }
     }
 #undef LAUNCH_STREAM
     return hipGetLastError();
 }
 
 template <int BM, int BN, int KG, int NS>
+static hipError_t setup_stream_rest();
+template <int BM, int BN, int KG, int NS>
 static hipError_t setup_stream()
+{
+    hipFuncAttributes fa;
+    if constexpr (BN == 96) {
+        for (const void* f : {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 0>,
+                              (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 2>}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());
+            if (e != hipSuccess) return e;
+            e = hipFuncGetAttributes(&fa, f);
+            if (e != hipSuccess) return e;
+            if (fa.numRegs > 256 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
+        }
+        return hipSuccess;
+    } else {
+        return setup_stream_rest<BM, BN, KG, NS>();
+    }
+}
+template <int BM, int BN, int KG, int NS>
+static hipError_t setup_stream_rest()
 {
     hipFuncAttributes fa;
     std::vector<const void*> fns = {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 0>,
@@ -1568,6 +1717,7 @@ hipError_t conv_setup()
     if ((e = setup_stream<64, 32, 2, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 128, 1, 5>()) != hipSuccess) return e;
+    if ((e = setup_stream<64, 96, 2, 3>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -1583,6 +1733,7 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
     if (KG == 4 && BM == 32 && BN == 32) return launch_stream<32, 32, 4, 4>(a, st);
     if (KG == 1 && BM == 64 && BN == 64) return launch_stream<64, 64, 1, 5>(a, st);
     if (KG == 1 && BM == 32 && BN == 128) return launch_stream<32, 128, 1, 5>(a, st);
+    if (KG == 2 && BM == 64 && BN == 96) return launch_stream<64, 96, 2, 3>(a, st);  // 3 stages of 40 KiB + 24 KiB of partial sums: one workgroup per CU
     return hipErrorInvalidValue;
 }
 

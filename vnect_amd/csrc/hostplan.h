@@ -365,7 +365,7 @@ struct TileChoice {
 };
 inline bool tile_shape_ok(int BM, int BN, int KG) { return (BM == 64 && BN == 64 && KG == 1) || (BM == 64 && BN == 32 && KG == 2) || (BM == 32 && BN == 32 && KG == 4) || (BM == 32 && BN == 128 && KG == 1); }
 inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int nphase, bool bf16, const std::string& name, const char* force,
-                              const char* plan)
+                              const char* plan, bool allow_deconv96 = false)
 {
     TileChoice c;
     const int nch = ntaps * cpt;
@@ -384,10 +384,19 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
         // launch only pays for the smallest, deepest layers)
         else if (!bf16 || (tiles <= 64 && kel >= 2048)) c.ks = std::min(5, nch);
     }
+    // The transposed conv in fp32 (round 4): 300 tiles of 64 x 64 on 256 CUs are TWO rounds for 44 of them; 64 x 96 tiles with two K groups
+    // and three accumulators per wave (conv.hip: NACC) are 200 tiles, ONE round of 1.5 block-K-loops per SIMD.  Only this layer takes the
+    // shape (no shortcut, one output tensor), only while its 64 x 64 plan needs a second round and the 96-wide one does not.
+    const bool deconv96_ok = !bf16 && nphase == 4 && cpt % 2 == 0 && round_up((int)nreal, 96) == round_up((int)nreal, 64);
+    if (deconv96_ok && allow_deconv96 && tiles > 256 && mt * (round_up((int)nreal, 96) / 96) * nphase <= 256) c.BM = 64, c.BN = 96, c.KG = 2, c.ks = 1;
     auto take = [&](const char* spec) {
         int fBM = 0, fBN = 0, fKG = 0, fks = 0;
-        if (sscanf(spec, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) == 4 && fks >= 1 && fks <= 8 && tile_shape_ok(fBM, fBN, fKG) && cpt % fKG == 0)
-            c.BM = fBM, c.BN = fBN, c.KG = fKG, c.ks = std::max(1, std::min(fks, nch / fKG));
+        if (sscanf(spec, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) != 4 || fks < 1 || fks > 8 || cpt % std::max(fKG, 1) != 0) return;
+        if (fBM == 64 && fBN == 96 && fKG == 2) {  // (the three-accumulator shape: where it is built for, never with K slabs)
+            if (deconv96_ok) c.BM = 64, c.BN = 96, c.KG = 2, c.ks = 1;
+            return;
+        }
+        if (tile_shape_ok(fBM, fBN, fKG)) c.BM = fBM, c.BN = fBN, c.KG = fKG, c.ks = std::max(1, std::min(fks, nch / fKG));
     };
     if (force) take(force);
     if (plan) {

@@ -337,11 +337,13 @@ using plan::round_up;
 using plan::same_pad;
 
 // Tile and K-split of a layer: plan::choose_tile (hostplan.h) with the tuning overrides VNECT_FORCE_TILE / VNECT_PLAN.
-void choose_tile(Layer& L, long long npix)
+void choose_tile(Layer& L, long long npix, bool allow96 = false)
 {
     (void)npix;
+    // (allow96: the transposed conv's three-accumulator shape, fp32 instruction path only -- not on a split-product handle, whose 64x64
+    // split-product loop is the faster one for this layer; VNECT_NO_DECONV96=1 restores the 64x64 plan for A/B runs)
     const plan::TileChoice c = plan::choose_tile(L.a.M, L.Nreal, L.a.ntaps, L.a.cpt, L.a.K, L.a.nphase, L.a.bf16 != 0, L.name,
-                                                 getenv("VNECT_FORCE_TILE"), getenv("VNECT_PLAN"));
+                                                 getenv("VNECT_FORCE_TILE"), getenv("VNECT_PLAN"), allow96 && !getenv("VNECT_NO_DECONV96"));
     L.BM = c.BM, L.BN = c.BN, L.KG = c.KG, L.a.ksplit = c.ks;
 }
 
@@ -788,7 +790,7 @@ int finalize_impl(vnect_handle* h)
         a.ldc = featCs, a.ldr = 0, a.relu_cols = 128, a.Nvalid = 191;
         L.Nreal = 191, L.Kreal = 4 * 256;
         L.flops = 2.0 * (double)S * 46 * 46 * 4 * 256 * 191;
-        choose_tile(L, (long long)S * 46 * 46);
+        choose_tile(L, (long long)S * 46 * 46, !h->x3);
         a.Npad = round_up(191, L.BN);
         a.w_phase_stride = (long long)a.Npad * a.K;
         std::vector<float> wp, bp, sc, sh;
@@ -799,9 +801,10 @@ int finalize_impl(vnect_handle* h)
             return VNECT_E_HIP;
         // bone-length features (vnect_model.py:198-209): inside this launch (conv.hip, FUSE = 2) where every workgroup has one tile,
         // i.e. up to 5 scales; as a launch of their own otherwise, and when per-layer read-back is requested
-        const long long deconv_items = (long long)((a.M + 63) / 64) * (a.Npad / 64) * 4;
-        const bool fuse_bone = L.BM == 64 && L.BN == 64 && L.KG == 1 && a.ksplit == 1 && deconv_items <= 512 && !h->keep_activations &&
-                               !getenv("VNECT_NO_BONE_FUSE");
+        const bool shape96 = L.BM == 64 && L.BN == 96 && L.KG == 2;
+        const long long deconv_items = (long long)((a.M + L.BM - 1) / L.BM) * (a.Npad / L.BN) * 4;
+        const bool fuse_bone = ((L.BM == 64 && L.BN == 64 && L.KG == 1 && deconv_items <= 512) || (shape96 && deconv_items <= 256)) && a.ksplit == 1 &&
+                               !h->keep_activations && !getenv("VNECT_NO_BONE_FUSE");
         a.bone = fuse_bone;
         if (fuse_bone) L.name = "res5c_deconv+bone_length";
         h->layers.push_back(L);
