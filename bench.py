@@ -300,6 +300,13 @@ def main():
     if world != args.gpus:
         args.gpus = world  # the launcher's word counts
 
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to STDOUT when its first communicator
+    # is made (torch's "nccl" process group in an N > 1 run, the library's in a pyramid run).  So file descriptor 1 points at stderr while
+    # the job runs, and the line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -612,7 +619,8 @@ def main():
             out["cpu_baseline"]["chosen_as"] = "the faster of cpu_baseline_port and cpu_baseline_framework on this box"
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     grp.close()
 
 

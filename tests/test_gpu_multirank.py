@@ -118,8 +118,8 @@ def test_bench_pyramid_one_rank_under_nccl():
                         "--warmup", "5", "--cpu-seconds", "0"], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # ONE line on stdout: RCCL's version banner goes to stderr with the rest
     d = json.loads(lines[0])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "rehearsal_pyramid_rccl_one_rank.json"), "w") as f:
