@@ -813,6 +813,69 @@ def test_tracking_loop_follows_planted_blobs():
         est.close()
 
 
+def test_planted_joints_through_every_way_of_running_a_frame():
+    """The geometric known answer of tests/planted.py (joint j ON the bright blob of colour j % 3) through every way the library runs a frame
+    -- each of them bit-equal to the synchronous call elsewhere in this file; here they must also be RIGHT: frames in flight on three lanes,
+    three videos on one handle, the split-product path, a pyramid sharded over three rank handles (each builds and runs ONE scale; the maps
+    are stacked in rank order as the exchange delivers them -- a swapped or stale slot would pull the merged peaks off the blobs), and one
+    scale alone.  Tolerance: one box pixel (the oracle's own: tests/test_planted.py)."""
+    from tests import planted
+    n = _native()
+    pw = planted.weights()
+    frames = [planted.frame(700 + k, H, W) for k, (H, W) in enumerate([(368, 368), (538, 368), (240, 320), (368, 368)])]
+
+    def on_blobs(j2, k, tol=1.0):
+        frame, centres = frames[k]
+        scaler = 368.0 / max(frame.shape[:2])
+        d = float(np.abs(j2 - planted.expected(centres)).max())
+        assert d <= tol / scaler, (k, d, scaler)
+
+    # frames in flight on three lanes (a new stream per frame would reset the filters; one stream: the blobs jump between frames, so
+    # only the first frame is unfiltered -- use one handle per check instead and submit the SAME frame three times: the filters settle on it)
+    h = _handle(BASELINE_SCALES, pw, lanes=3)
+    for k in range(3):
+        h.upload_frame(k, frames[0][0])
+        h.submit_resident(k, T0 + k / 30, T0 + k / 30 + 0.001)
+    for k in range(3):
+        on_blobs(h.collect()[0], 0)
+    # three videos on one handle: stream s sees frame s
+    h.reset_filters()
+    for s_ in range(3):
+        h.upload_frame(s_, frames[s_][0])
+        h.submit_stream(s_, s_, T0 + 10 + s_, T0 + 10 + s_ + 0.001)
+    for s_ in range(3):
+        st, j2, j3 = h.collect_stream()
+        on_blobs(j2, st)
+    h.close()
+    # the split-product path and a single scale
+    for kw, scales in ((dict(precision=n.FP32_SPLIT), BASELINE_SCALES), (dict(), [1.0]), (dict(precision=n.BF16), [1.0, 0.8])):
+        h = _handle(scales, pw, **kw)
+        for k in range(len(frames)):
+            h.reset_filters()
+            on_blobs(h.infer(frames[k][0], T0 + 20 + k, T0 + 20 + k + 0.001)[0], k, tol=8.0 if kw.get("precision") == n.BF16 else 1.0)
+        h.close()
+    # pyramid sharded over three rank handles: rank r pre-processes and runs scale r; the stack in rank order is what the exchange delivers
+    ranks = [n.Handle(BASELINE_SCALES, pyramid=(r, 3)) for r in range(3)]
+    for hh in ranks:
+        hh.set_weights(pw)
+        hh.finalize()
+    for k in range(len(frames)):
+        maps = []
+        for hh in ranks:
+            b, scaler, (ox, oy) = hh.preprocess(frames[k][0])
+            maps.append(hh.forward(b)[0])
+        ranks[0].reset_filters()
+        j2, j3 = ranks[0].postprocess(np.stack(maps), T0 + 30 + k, T0 + 30 + k + 0.001, scaler, ox, oy)
+        on_blobs(j2, k)
+        if k == 1:  # the wrong slot order is NOT right: the test can see what it claims to see
+            ranks[0].reset_filters()
+            w2, _ = ranks[0].postprocess(np.stack([maps[1], maps[0], maps[2]]), T0 + 40, T0 + 40.001, scaler, ox, oy)
+            frame, centres = frames[k]
+            assert float(np.abs(w2 - planted.expected(centres)).max()) > 8.0 / (368.0 / max(frame.shape[:2]))
+    for hh in ranks:
+        hh.close()
+
+
 # ------------------------------------------------------------------------------------------ pyramid sharding
 def test_pyramid_shards_reassemble(weights, oracle_net):
     """configs[3] without a second GPU: three rank-handles (one scale each) run their own pre-processing and conv
