@@ -145,10 +145,10 @@ def test_bench_gpus_2_on_a_one_gpu_box_fails_fast():
     dt = time.time() - t0
     assert r.returncode != 0 and "HIP device 1 is missing" in r.stderr and "exposes 1" in r.stderr, (r.returncode, r.stderr[-1500:])
     assert not r.stdout.strip()
-    assert dt < 60, dt                              # one torch import in a throw-away child, no rendezvous
+    assert dt < 240, dt                             # one torch import in a throw-away child (minutes only on a box that has never imported torch), no rendezvous time-out
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
                        env=_clean_env(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and "needs HIP device 1" in r.stderr, (r.returncode, r.stderr[-1500:])
-    assert time.time() - t0 < 60
+    assert time.time() - t0 < 240
