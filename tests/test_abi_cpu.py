@@ -166,3 +166,6 @@ def test_rccl_copy_already_mapped_is_reused(tmp_path):
     r = subprocess.run([sys.executable, "-c", code, "-"], capture_output=True, text=True, env=dict(env, VNECT_RCCL_LIB=bundled), timeout=300)
     c = json.loads(r.stdout.strip().splitlines()[-1])
     assert os.path.samefile(c["path"], bundled) and c["reused"] is False, c
+    # ... and one that cannot be honoured is an error (VNECT_E_COMM), not a reason to pick another copy
+    r = subprocess.run([sys.executable, "-c", code, "-"], capture_output=True, text=True, env=dict(env, VNECT_RCCL_LIB="/nonexistent/librccl.so"), timeout=300)
+    assert r.returncode != 0 and "librccl.so not available" in r.stderr and "code %d" % _native.E_COMM in r.stderr, r.stderr[-800:]
