@@ -1,0 +1,41 @@
+"""Long soak of the product path (tuning / release aid; runs on the GPU box, ~75 s): 20 000 synchronous frames twice -- the two runs must
+agree bit for bit -- and the same 20 000 frames three in flight on three lanes -- must equal the sequential result --, fp32 and bf16.
+tests/test_gpu_parity.py::test_soak_three_lanes_deterministic is the short form (3 000 frames) the suite runs."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests import helpers
+from vnect_amd import _native
+from vnect_amd.weights import synthetic_weights
+w = synthetic_weights()
+for prec, name in ((_native.FP32, "fp32"), (_native.BF16, "bf16")):
+    h = _native.Handle([1.0, 0.8, 0.6], precision=prec, lanes=3, num_frame_slots=4)
+    h.set_weights(w); h.finalize()
+    frames = [helpers.synth_frame(100 + k, smooth=True) for k in range(4)]
+    for k in range(4): h.upload_frame(k, frames[k])
+    ref = None
+    t0 = time.time()
+    N = 20000
+    # synchronous frames with a fixed period: the joints of frame i depend on the filter history, which is periodic only in the raw
+    # arg-max; so check determinism by running the SAME sequence twice
+    outs = []
+    for rep in range(2):
+        h.reset_filters()
+        acc = np.zeros((21, 2))
+        for i in range(N):
+            j2, j3 = h.infer_resident(i % 4, 10.0 + i / 30, 10.0 + i / 30 + 1e-3)
+            acc += j2
+        outs.append((acc.copy(), j2.copy(), j3.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    # three frames in flight
+    h.reset_filters()
+    acc2 = np.zeros((21, 2))
+    for i in range(N):
+        if i >= 3:
+            acc2 += h.collect()[0]
+        h.submit_resident(i % 4, 10.0 + i / 30, 10.0 + i / 30 + 1e-3)
+    for _ in range(3):
+        acc2 += h.collect()[0]
+    assert np.array_equal(acc2, outs[0][0]), "pipelined != sequential"
+    print(name, "soak ok:", 3 * N, "frames, %.1f s" % (time.time() - t0), flush=True)
+    h.close()
