@@ -36,6 +36,7 @@ PEAK_HBM = 8000.0              # GB/s
 BF16_BYTES_PER_FRAME = 29.2e6 + 2 * 3 * 58.7e6
 # committed rocprofv3 summaries are named profiles/rNN<prefix>_{kernel_stats.csv,conv_roofline.json,traffic.json} (tools/profile_round.sh)
 PROFILE_PREFIX = {"fp32": "", "bf16": "_bf16", "fp32_split": "_split"}
+DUMP_T0 = 1.6e9                # first timestamp of the --dump-joints frames (fresh filter banks, so any value serves)
 
 
 def cpu_baseline(weights, budget_s):
@@ -81,8 +82,10 @@ def cpu_framework_baseline(weights, budget_s):
             maps = torch_net.forward(weights, batch, dtype=torch.float32).numpy()
         return est.postprocess(maps, t, t, scaler, off[0], off[1])
 
-    # the best this host can do, not an assumed cap: a short sweep over the intra-op thread count (2 frames each after one
-    # warm-up frame), then the sample on the fastest
+    # the best this host can do, not an assumed cap: a sweep over the intra-op thread count -- one warm-up frame, then 20 frames per
+    # setting (fewer only where a setting is so slow that 20 frames would take more than 4 s: it has lost by then) -- and the sample
+    # on the fastest, as the MEDIAN of five windows with their spread beside it (round 4's two-frame sweep and single window
+    # disagreed with each other by up to 2x)
     sweep, clk = {}, 1.0
     for th in sorted({t for t in (8, 16, 32, 64, 128, ncores) if t <= ncores}):
         if sweep and (th > 128 or sweep[max(sweep)] < 0.5 * max(sweep.values())):
@@ -90,26 +93,30 @@ def cpu_framework_baseline(weights, budget_s):
         torch.set_num_threads(th)
         clk += 1
         frame(0, clk)
-        t0 = time.perf_counter()
-        for k in range(2):
+        k, t0 = 0, time.perf_counter()
+        while k < 20 and (k < 3 or time.perf_counter() - t0 < 4.0):
             clk += 1
             frame(k, clk)
-        sweep[th] = round(2 / (time.perf_counter() - t0), 2)
+            k += 1
+        sweep[th] = round(k / (time.perf_counter() - t0), 2)
     threads = max(sweep, key=sweep.get)
     torch.set_num_threads(threads)
     frame(0, clk + 1)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        frame(n, clk + 2 + n / 30)
-        n += 1
-        dt = time.perf_counter() - t0
-        if (dt >= budget_s and n >= 3) or n >= 400:
-            break
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+    windows, n, t_all = [], 0, time.perf_counter()
+    for w in range(5):
+        k, t0 = 0, time.perf_counter()
+        while (time.perf_counter() - t0 < budget_s / 5 or k < 3) and k < 80:
+            frame(n, clk + 2 + n / 30)
+            n += 1
+            k += 1
+        windows.append(k / (time.perf_counter() - t0))
+    dt = time.perf_counter() - t_all
+    windows.sort()
+    return {"value": round(windows[2], 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "implementation": "torch-CPU (oneDNN) fp32 restatement of the network (tests/torch_net.py) + the oracle's pre / post-processing",
-            "thread_sweep_frames_per_s": sweep,
-            "sample": "%d frames of the same workload in %.1f s on %d threads of %d host cores (torch %s; fastest of the sweep %s)"
-                      % (n, dt, threads, ncores, torch.__version__, sweep)}
+            "thread_sweep_frames_per_s": sweep, "windows_frames_per_s": [round(x, 2) for x in windows],
+            "sample": "%d frames of the same workload in %.1f s on %d threads of %d host cores, median of 5 windows (min %.2f, max %.2f; torch %s; "
+                      "thread sweep, 20 frames per setting: %s)" % (n, dt, threads, ncores, windows[0], windows[-1], torch.__version__, sweep)}
 
 
 def committed(pattern, key):
@@ -281,6 +288,10 @@ def main():
                     help="comma-separated pyramid (default 1.0,0.8,0.6 = BASELINE.json).  Anything else is a REHEARSAL, labelled as such "
                          "in the line: `--pyramid --scales 1.0 --gpus 1` runs the whole configs[3] machinery -- torch's \"nccl\" process "
                          "group, PyramidJob, ncclCommInitRank + one ncclAllGather per frame, timed loop, profile -- with ONE rank on one GPU")
+    ap.add_argument("--dump-joints", default=None, metavar="PREFIX",
+                    help="parity evidence for the N > 1 tests (tests/test_gpu_multigpu.py): behind the timed region every rank runs 8 more "
+                         "frames of its stream on fresh filter banks at fixed timestamps and writes PREFIX.<leg>.rank<r>.npz (j2, j3); a "
+                         "single-GPU run of the same seeds must reproduce them bit for bit")
     ap.add_argument("--pyramid-both", action="store_true",
                     help="--pyramid with BOTH exchange forms in one job (rccl first, then p2p): the side-by-side SURVEY 8e asks for "
                          "from one 3-GPU lease; `value` is the RCCL all-gather form (the one north_star names), p2p under \"pyramid_p2p\"")
@@ -414,11 +425,23 @@ def main():
         assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
         return elapsed, np.diff(np.array(stamps)) * 1e3
 
+    def dump_joints(hh, leg):
+        """--dump-joints: 8 frames of this rank's stream on fresh filter banks, fixed timestamps (DUMP_T0 + k / 30); outside every timed
+        region.  A pyramid job's ranks all take part (each inference contains the exchange)."""
+        if not args.dump_joints:
+            return
+        hh.reset_filters()
+        js = [hh.infer_resident(k % nslots, DUMP_T0 + k / 30, DUMP_T0 + k / 30 + 1e-3) for k in range(8)]
+        hh.reset_filters()
+        np.savez("%s.%s.rank%d.npz" % (args.dump_joints, leg, rank), j2=np.stack([a for a, _ in js]), j3=np.stack([b for _, b in js]),
+                 device=np.int64(local_rank), stream=np.int64(stream))
+
     elapsed, lat = timed(h, args.steps, args.warmup)
+    dump_joints(h, ("pyramid_" + args.exchange) if args.pyramid else "replica")
 
     # pipelined rate of the same stream (three frames in flight on three lanes: they overlap, only the filter kernels stay
     # ordered), reported beside the synchronous one
-    pipelined = pcie = two_streams = None
+    pipelined = pcie = pinned = two_streams = None
     if not args.no_aux and not args.pyramid:
         barrier()
         p0 = time.perf_counter()
@@ -442,6 +465,18 @@ def main():
             clock[0] += 1 / 30
             h.infer(host_frames[i % nslots], clock[0], clock[0] + 1e-3)
         pcie = nh / (time.perf_counter() - q0)
+        # ... and from the handle's PINNED capture buffers (vnect_frame_buffer: where a capture pipeline would put its frames): the same
+        # call, the frame still crosses PCIe every step, but no CPU copy comes first
+        bufs = [h.frame_buffer(i, 368, 368) for i in range(2)]
+        for i in range(2):
+            bufs[i][...] = host_frames[i]
+        for i in range(5 + nh):
+            if i == 5:
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+            clock[0] += 1 / 30
+            h.infer(bufs[i % 2], clock[0], clock[0] + 1e-3)
+        pinned = nh / (time.perf_counter() - q0)
         for k in range(nslots):  # vnect_infer stages its frame in slot 0: restore the resident set
             h.upload_frame(k, host_frames[k])
         # two independent video streams sharing this GPU (two handles, two host threads): what the idle CUs between the
@@ -501,6 +536,7 @@ def main():
         for k in range(nslots):
             h.upload_frame(k, host_frames[k])
         e2, lat2 = timed(h, args.steps, args.warmup)
+        dump_joints(h, "pyramid_p2p")
         pyramid_p2p = {"value": round(args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
                        "exchange": "peer writes over xGMI (exchange_kernel)",
                        "latency_ms": {"p50": round(float(np.percentile(lat2, 50)), 4), "p95": round(float(np.percentile(lat2, 95)), 4)}}
@@ -547,6 +583,7 @@ def main():
                                    if args.pyramid else None),
             "rccl_library": rccl_lib,
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
+            "pcie_inclusive_from_pinned_capture_buffer_frames_per_s_per_gpu": None if pinned is None else round(pinned, 2),
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
             "three_streams_on_one_handle_frames_per_s": None if streams3 is None else round(streams3, 2),
@@ -566,12 +603,12 @@ def main():
         out["bf16"] = {"value": round(args.steps / eb, 2), "unit": "frames/s", "ms_per_step": round(eb / args.steps * 1e3, 4),
                        "dtype": "bf16", "steps": args.steps, "warmup": args.warmup,
                        "config": "BASELINE.json configs[2]: same frames and scales, bf16 operands / activations, fp32 accumulate, fp32 "
-                                 "final maps, f64 post-processing; tolerance-gated against fp32 in tests/test_gpu_parity.py",
+                                 "final maps, f64 post-processing; tolerance-gated against fp32 in tests/test_gpu_bf16.py",
                        "latency_ms": {"p50": round(float(np.percentile(latb, 50)), 4), "p95": round(float(np.percentile(latb, 95)), 4)},
                        "roofline": roofline(timb, nprof, "bf16")}
 
     # The split-product fp32 path (VNECT_FP32_SPLIT: fp32 tensors and accumulators, fp32-class results -- gated like fp32 in
-    # tests/test_gpu_parity.py -- with the products of the big layers on the bf16 matrix pipe), measured exactly like the headline.
+    # tests/test_gpu_split.py -- with the products of the big layers on the bf16 matrix pipe), measured exactly like the headline.
     # Beside the headline, never `value`: the headline stays the fp32 INSTRUCTION path until the judge rules on this one.
     if args.gpus == 1 and args.precision == "fp32" and not args.no_aux and not args.pyramid:
         hs = make("fp32_split", use_graph=graph_mode, lanes=3)
@@ -595,7 +632,7 @@ def main():
                              "dtype": "f32 storage and accumulate; products by exact 3-way bf16 splits (6 of 9 piece products) on v_mfma_f32_32x32x16_bf16",
                              "steps": args.steps, "warmup": args.warmup,
                              "config": "BASELINE.json configs[1] workload; precision = VNECT_FP32_SPLIT; parity gates of the fp32 path "
-                                       "(tests/test_gpu_parity.py::test_split_product_path_meets_the_fp32_gates: error vs the oracle equal to the fp32 instruction's)",
+                                       "(tests/test_gpu_split.py::test_split_product_path_meets_the_fp32_gates: error vs the oracle equal to the fp32 instruction's)",
                              "latency_ms": {"p50": round(float(np.percentile(lats, 50)), 4), "p95": round(float(np.percentile(lats, 95)), 4)},
                              "pipelined_frames_per_s_per_gpu": round(split_pipelined, 2),
                              "roofline": roofline(tims, nprof, "fp32_split")}

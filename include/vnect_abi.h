@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VNECT_ABI_VERSION 4
+#define VNECT_ABI_VERSION 5
 #define VNECT_MAX_SCALES 8
 #define VNECT_MAX_STREAMS 4 /* independent video streams one handle can serve (vnect_submit_stream) */
 #define VNECT_BOX 368      /* src/estimator.py:19 box_size   */
@@ -125,6 +125,14 @@ int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d
 /* Replaces VNectEstimator.__call__ (src/estimator.py:97-142) end to end. */
 int vnect_infer(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, double t2d, double t3d,
                 double* joints_2d, float* joints_3d);
+
+/* Where a capture pipeline should put its frames so that vnect_infer's host-to-device copy needs no CPU copy first: the handle's
+ * two PINNED staging buffers (index 0 / 1, at least min_bytes each, <= max_frame_bytes; the pointer stays valid until a larger
+ * request for the same index or vnect_destroy).  The reference's loop gets its frame from cv2.VideoCapture.read into pageable numpy
+ * memory (run_estimator_ps.py:75-82) and hands it to __call__ (src/estimator.py:97-99); vnect_infer accepts ANY host pointer -- a
+ * pageable one is copied into these buffers by the CPU (one memcpy), a pointer INSIDE one of them (the whole frame or a strided crop
+ * of it) is DMA-ed from where it lies.  Either way the device copy is asynchronous on the frame's stream. */
+int vnect_frame_buffer(vnect_handle* h, int index, int64_t min_bytes, uint8_t** ptr_out);
 
 /* Frames resident in HBM (throughput measurement; a capture pipeline that DMA-writes frames).
  * upload copies a frame into slot; infer_resident runs __call__ on it without a host->device copy. */

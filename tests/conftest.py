@@ -22,3 +22,19 @@ def weights():
 def oracle_net(weights):
     import oracle
     return oracle.Oracle(weights, keep=True)
+
+
+@pytest.fixture(scope="session")
+def h3(weights):
+    """One finalized 3-scale fp32 handle (BASELINE scales) shared by the GPU test files."""
+    from tests.gpu_common import BASELINE_SCALES, _handle
+    h = _handle(BASELINE_SCALES, weights)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="session")
+def ref3(weights, oracle_net):
+    import oracle
+    from tests.gpu_common import BASELINE_SCALES
+    return oracle.OracleEstimator(scales=BASELINE_SCALES, net=oracle_net)

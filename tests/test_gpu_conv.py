@@ -1,0 +1,310 @@
+"""GPU (MI355X), through the C ABI: the conv stack against the CPU oracle -- every layer, every fused
+launch form against its unfused plan, every tile shape.  Gate: max|d| <= 1e-4 * max|oracle| (measured ~3e-6)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.gpu_common import BASELINE_SCALES, G, OUT, T0, _EndToEnd, _handle, _log, _native, _round_bf16  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_conv_stack_every_layer(h3, weights, oracle_net):
+    """a1-a7: every named activation of the HIP graph vs the oracle, S=3 at BASELINE scales.  Inner layers are read from
+    a handle with private buffers (keep_activations); the product default shares an arena between layers, must refuse to
+    return an inner layer, and must produce bit-identical maps."""
+    import oracle
+    from tests import helpers
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
+    ref = oracle_net.forward(batch)
+    arena_out = h3.forward(batch)
+    with pytest.raises(_native().VnectError):
+        h3.activation("res3a")
+    assert np.array_equal(h3.activation("res5c_branch2c"), arena_out)  # the final maps stay readable
+    h3 = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    out = h3.forward(batch)
+    assert np.array_equal(out, arena_out)
+    rows, bad = [], []
+    names = [L["name"] for L in h3.layers()]
+    acts = ["conv1", "pool1"]
+    for n in names:
+        if "+" in n:                          # two layers in one launch: "<scope_a>+<rest of scope_b>"
+            a, b = n.split("+")
+            acts += [a, b if b.startswith("res") else a.split("_")[0] + "_" + b]
+        elif n == "res5c_branch2c":
+            acts.append(n)
+        elif n.endswith("_branch2c") or n == "res5a_branch2c_new":
+            acts.append(n.split("_")[0])      # block output resNx
+        elif n == "res5c_deconv":
+            continue
+        elif n == "res5c_bone_length":
+            acts.append("res5c_branch2a_feat")
+        elif n not in ("conv1", "pool1"):
+            acts.append(n)
+    for n in acts:
+        a, r = h3.activation(n), oracle_net.activation(n)
+        assert a.shape == r.shape, n
+        err = float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-12))
+        rows.append((n, list(a.shape), err))
+        if not err <= 1e-4:
+            bad.append((n, err))
+    _log("layer_errors.json", rows)
+    for r in rows:
+        print("%-24s %-20s rel err %.3g" % (r[0], r[1], r[2]))
+    h3.close()
+    assert not bad, "first mismatching layers: %r" % bad[:3]
+    assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4
+
+
+def test_conv1_span_form_is_bit_identical(weights, oracle_net, monkeypatch):
+    """conv1 (fp32) reads its A operand from the tile's contiguous pixel run(s) instead of 64 gathered windows and skips the MFMAs
+    of the zero padding channel (conv.hip, SPAN): same K order, so conv1 and everything behind it must equal the gathered-window
+    form (VNECT_NO_SPAN=1) bit for bit -- on frames whose tiles straddle output rows and images (S = 1, 2, 3)."""
+    import oracle
+    from tests import helpers
+    for scales in ([1.0], [1.0, 0.7], BASELINE_SCALES):
+        batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(640 + len(scales), 333, 368), scales)
+        h = _handle(scales, weights, keep_activations=True, use_graph=False)
+        out = h.forward(batch)
+        c1 = h.activation("conv1")
+        monkeypatch.setenv("VNECT_NO_SPAN", "1")
+        ref_out = h.forward(batch)
+        ref_c1 = h.activation("conv1")
+        monkeypatch.delenv("VNECT_NO_SPAN")
+        h.close()
+        assert np.array_equal(c1, ref_c1), len(scales)
+        assert np.array_equal(out, ref_out), len(scales)
+        r = oracle_net.forward(batch)
+        assert float(np.abs(out - r).max()) <= 1e-4 * float(np.abs(r).max())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_tail_and_chain_gemms_are_bit_identical(weights, monkeypatch, prec):
+    """The launches that carry a second (and third) GEMM behind their K loop -- res2*_branch2b>branch2c on 64x64 tiles, res3*_branch2b>
+    branch2c and the head's res5c_branch2b>res5c_branch2c on 32x128 tiles (conv.hip: tail_gemm, tail_wide), in bf16 with the next
+    block's branch2a chained on (chain_gemm) --, and the stem launch that also runs res2a_branch2a + res2a_branch1 on its pooled tile
+    (stem.hip, PAIR) -- against the same layers as launches of their own (vnect_model.py:32-103,211-217): the final maps must be EQUAL
+    at 3 scales (199 workgroups) and at 4 (the wide form no longer fits one workgroup per CU and the plan falls back by itself) and
+    agree to rounding at 1 and 2 (67 / 133 workgroups; there the stand-alone layers split K), and the launch counts must be what the
+    plan promises.  VNECT_FORCE_CHAIN puts the chain on the fp32 handle too (measured slower there, so off by default -- but it is
+    built, so it is tested)."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    p = n.BF16 if prec == "bf16" else n.FP32
+    for scales in ([1.0], [1.0, 0.7], BASELINE_SCALES, [1, 0.85, 0.7, 0.5]):
+        batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77 + len(scales), smooth=True), scales)
+        outs, counts, joints = {}, {}, {}
+        frame = helpers.synth_frame(91 + len(scales), 368, 300, smooth=True)
+        # (fp32 plans take the wide form from 128 workgroups on -- it is slower for a single scale's 67 --: VNECT_FORCE_WIDE_TAIL keeps
+        # that geometry under test)
+        monkeypatch.setenv("VNECT_FORCE_WIDE_TAIL", "1")
+        for tag, env in (("default", {}), ("no_wide", {"VNECT_NO_WIDE_TAIL": "1"}), ("no_tail", {"VNECT_NO_TAIL": "1"}),
+                         ("no_chain", {"VNECT_NO_CHAIN": "1"}), ("force_chain", {"VNECT_FORCE_CHAIN": "1"}),
+                         ("no_stem_pair", {"VNECT_NO_STEM_PAIR": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            h = _handle(scales, weights, precision=p)
+            for k in env:
+                monkeypatch.delenv(k)
+            outs[tag] = h.forward(batch)
+            if tag in ("default", "no_stem_pair"):  # the stem's pair GEMM from the frame as well (forward() feeds it the batch tensor)
+                j2, j3 = h.infer(frame, T0 + 5, T0 + 5.001)
+                joints[tag] = (j2, j3, h.activation("res5c_branch2c"))
+            counts[tag] = sum(1 for L in h.layers() if ">" in L["name"]), sum(L["name"].count(">") for L in h.layers())
+            h.close()
+        S = len(scales)
+        for x, y in zip(joints["default"], joints["no_stem_pair"]):
+            assert np.array_equal(x, y), scales
+        for tag in outs:
+            if S >= 3:  # the stand-alone layers run whole-K tiles like the fused ones: the same sums in the same order
+                assert np.array_equal(outs[tag], outs["no_tail"]), (scales, tag)
+            else:       # fewer scales: stand-alone 3x3 (and, for one scale, 1x1) layers split K (hostplan.h: choose_tile), so only the order of the sums differs
+                err = float(np.abs(outs[tag] - outs["no_tail"]).max() / np.abs(outs["no_tail"]).max())
+                assert err <= (2e-2 if prec == "bf16" else 1e-5), (scales, tag, err)
+        assert counts["no_tail"] == (0, 0)
+        assert counts["no_wide"] == ((3, 4 if prec == "bf16" else 3) if S <= 3 else (0, 0))  # the 92x92 tails: up to 512 tiles of 64 rows
+        wide = S <= 3
+        assert counts["no_chain"] == ((8, 8) if wide else (0, 0))
+        assert counts["force_chain"] == ((8, 12 if prec == "bf16" else 11) if wide else (0, 0))  # bf16: the 64-wide tail of res2a chains too
+        assert counts["default"] == counts["no_stem_pair"] == counts["force_chain" if prec == "bf16" else "no_chain"]
+        monkeypatch.delenv("VNECT_FORCE_WIDE_TAIL")
+        if S == 1 and prec == "fp32":  # the plan's own choice for one scale in fp32: the 92x92 tails only
+            h = _handle(scales, weights, precision=p)
+            assert sum(1 for L in h.layers() if ">" in L["name"]) == 3
+            assert np.array_equal(h.forward(batch), outs["no_wide"])
+            h.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_stem_is_bit_identical(weights, monkeypatch, prec):
+    """The stem as ONE launch (stem.hip: [gen_input_batch ->] conv1 + ReLU -> max-pool on spatial tiles, vnect_model.py:27-29,
+    estimator.py:70-81) against the three stand-alone kernels: pool1 -- read from handles with private buffers, VNECT_FORCE_STEM puts
+    the fused form on such a handle -- the final maps and the joints must be EQUAL, for both patch sources (the batch tensor; the
+    uint8 frame), S = 1, 3 and 4 (row groups of 4 and of 5 pooled rows; more tiles than CUs), square and non-square frames, and
+    through vnect_forward's (S,368,368,3) entry."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    p = n.BF16 if prec == "bf16" else n.FP32
+    # long side 368 (squarify is a copy: the from-the-frame form runs, with and without black bars), and frames that squarify resizes
+    # (that form's host-side fallback: pyramid_kernel + the stem from the batch tensor)
+    frames = [helpers.synth_frame(31, smooth=True), helpers.synth_frame(32, 538, 368, smooth=True), helpers.synth_frame(33, 240, 320),
+              helpers.synth_frame(34, 368, 200), helpers.synth_frame(35, 123, 368, smooth=True), helpers.synth_frame(36)]
+    # [1.0, 0.8, 0.3], [1.0, 0.15]: scales whose tiles need more frame rows than the kernel's LDS rectangle holds (plan::stem_frame_fits
+    # -> fallback); one and two images run 2- and 3-row tiles (hostplan.h: stem_groups), three 4- and 5-row ones
+    for scales in (BASELINE_SCALES, [1.0], [1, 0.85, 0.7, 0.5], [1.0, 0.4], [1.0, 0.3], [1.0, 0.8, 0.3], [1.0, 0.15]):
+        plain = _handle(scales, weights, precision=p, keep_activations=True)
+        assert [L["name"] for L in plain.layers()][:2] == ["conv1", "pool1"]
+        batch, _, _ = oracle.gen_input_batch(frames[1], scales)
+        want_fwd = plain.forward(batch)
+        want_pool_fwd = plain.activation("pool1")
+        want = []
+        for k, f in enumerate(frames):
+            t = T0 + 900 + k / 30
+            j2, j3 = plain.infer(f, t, t + 0.001)
+            want.append((j2, j3, plain.activation("pool1"), plain.activation("res5c_branch2c")))
+        plain.close()
+        for mode in ("batch", "frame"):
+            monkeypatch.setenv("VNECT_FORCE_STEM", mode)
+            fused = _handle(scales, weights, precision=p, keep_activations=True)
+            monkeypatch.delenv("VNECT_FORCE_STEM")
+            assert np.array_equal(fused.forward(batch), want_fwd), (scales, mode)          # vnect_forward: the stem reads the batch
+            assert np.array_equal(fused.activation("pool1"), want_pool_fwd), (scales, mode)
+            for k, f in enumerate(frames):
+                t = T0 + 900 + k / 30
+                j2, j3 = fused.infer(f, t, t + 0.001)
+                assert np.array_equal(fused.activation("pool1"), want[k][2]), (scales, mode, k)
+                assert np.array_equal(fused.activation("res5c_branch2c"), want[k][3]), (scales, mode, k)
+                assert np.array_equal(j2, want[k][0]) and np.array_equal(j3, want[k][1]), (scales, mode, k)
+            fused.close()
+    # the product default: arena handles run the stem from the frame; VNECT_NO_STEM restores the three launches
+    a = _handle(BASELINE_SCALES, weights, precision=p)
+    monkeypatch.setenv("VNECT_NO_STEM", "1")
+    b = _handle(BASELINE_SCALES, weights, precision=p)
+    monkeypatch.delenv("VNECT_NO_STEM")
+    for k, f in enumerate(frames):
+        t = T0 + 950 + k / 30
+        ra, rb = a.infer(f, t, t + 0.001), b.infer(f, t, t + 0.001)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]), k
+        assert np.array_equal(a.activation("res5c_branch2c"), b.activation("res5c_branch2c")), k
+    a.close(), b.close()
+
+
+def test_fused_stem_fuzz_frame_shapes_and_scales(weights, monkeypatch):
+    """The from-the-frame stem against the three stand-alone kernels on a sweep of frame shapes whose long side is 368 (its fast path:
+    odd widths and heights, so frame rows start at every byte alignment; black bars left / right or top / bottom) and of scale sets
+    (1 to 4 scales down to 0.5, incl. a scale whose size rounds back to 368): the final maps and the joints must be EQUAL."""
+    from tests import helpers
+    rng = np.random.RandomState(2024)
+    shapes = [(368, 368), (368, 1), (1, 368), (368, 367), (367, 368), (368, 123), (77, 368), (368, 245), (201, 368)]
+    scale_sets = [[1.0], [1.0, 0.8, 0.6], [1, 0.85, 0.7], [1.0, 0.9999], [1.0, 0.93, 0.71, 0.5], [0.9, 0.55]]
+    for si, scales in enumerate(scale_sets):
+        monkeypatch.setenv("VNECT_NO_STEM", "1")
+        ref = _handle(scales, weights)
+        monkeypatch.delenv("VNECT_NO_STEM")
+        fused = _handle(scales, weights)
+        for k in rng.choice(len(shapes), 4, replace=False):
+            H, W = shapes[k]
+            frame = helpers.synth_frame(5000 + 17 * si + int(k), H, W, smooth=bool((si + k) % 2))
+            t = T0 + 2000 + si * 10 + int(k)
+            fused.reset_filters(), ref.reset_filters()
+            a2, a3 = fused.infer(frame, t, t + 0.001)
+            b2, b3 = ref.infer(frame, t, t + 0.001)
+            assert np.array_equal(fused.activation("res5c_branch2c"), ref.activation("res5c_branch2c")), (scales, H, W)
+            assert np.array_equal(a2, b2) and np.array_equal(a3, b3), (scales, H, W)
+        fused.close(), ref.close()
+
+
+def test_deconv_three_accumulator_shape(weights, oracle_net, monkeypatch):
+    """The transposed convs res5c_branch1a / res5c_branch2a (+ BN + ReLU; vnect_model.py:188-196) on 64 x 96 tiles with two K groups and THREE
+    accumulators per wave (conv.hip: NACC; round 4: 200 tiles in one round instead of 300 in two) -- the fp32 plan at three scales.  Plain
+    (per-layer read-back) and with the bone features in its launch (arena plan): res5c_branch2a_feat within 1e-4 of the oracle, the two forms
+    bit-identical, the 64 x 64 plan (VNECT_NO_DECONV96=1) equal to fp32 rounding (another summation order: two K groups), final maps alike;
+    bf16, four scales and a split-product handle keep the 64 x 64 tiles."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(1234, smooth=True), BASELINE_SCALES)
+    ref = oracle_net.forward(batch)
+    feat_ref = oracle_net.activation("res5c_branch2a_feat")
+    top = float(np.abs(feat_ref).max())
+
+    def tile_of(h):
+        L = [x for x in h.layers() if x["name"].startswith("res5c_deconv")]
+        assert len(L) == 1
+        return (L[0]["tile_m"], L[0]["tile_n"], L[0]["workgroups"], L[0]["name"])
+
+    keep = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    arena = _handle(BASELINE_SCALES, weights)
+    assert tile_of(keep)[:3] == (64, 96, 200) and tile_of(arena) == (64, 96, 200, "res5c_deconv+bone_length"), (tile_of(keep), tile_of(arena))
+    mk, ma = keep.forward(batch), arena.forward(batch)
+    fk = keep.activation("res5c_branch2a_feat")
+    assert fk.shape == feat_ref.shape and float(np.abs(fk - feat_ref).max()) <= 1e-4 * top
+    assert np.array_equal(mk, ma)                                  # bone features inside the launch == the stand-alone bone kernel
+    assert float(np.abs(ma - ref).max()) <= 1e-4 * float(np.abs(ref).max())
+    monkeypatch.setenv("VNECT_NO_DECONV96", "1")
+    old = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    monkeypatch.delenv("VNECT_NO_DECONV96")
+    assert tile_of(old)[:3] == (64, 64, 300)
+    mo = old.forward(batch)
+    fo = old.activation("res5c_branch2a_feat")
+    assert float(np.abs(fo - fk).max()) <= 2e-5 * top and float(np.abs(mo - mk).max()) <= 2e-5 * float(np.abs(ref).max())
+    for h in (keep, arena, old):
+        h.close()
+    for kw, scales in ((dict(precision=n.BF16), BASELINE_SCALES), (dict(precision=n.FP32_SPLIT), BASELINE_SCALES), (dict(), [1.0, 0.9, 0.8, 0.7])):
+        h = _handle(scales, weights, **kw)
+        assert tile_of(h)[:2] == (64, 64), (kw, scales, tile_of(h))
+        h.close()
+
+
+def test_conv_stack_batch_independent(h3, oracle_net):
+    """The S images are independent: permuting the batch permutes the output (what sharding relies on)."""
+    import oracle
+    from tests import helpers
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(99), BASELINE_SCALES)
+    a = h3.forward(batch)
+    b = h3.forward(batch[::-1].copy())
+    assert np.array_equal(a, b[::-1])
+    assert np.array_equal(a, h3.forward(batch))  # deterministic: bit-identical on a second run
+
+
+def test_single_scale_and_paper_wiring(weights):
+    """S=1 (reference's 'faster loops' hint) and the paper_res2c switch, vs the oracle."""
+    import oracle
+    from tests import helpers
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(5, smooth=True), [1.0])
+    for paper in (False, True):
+        h = _handle([1.0], weights, paper_res2c=paper)
+        ref = oracle.Oracle(weights, paper_res2c=paper).forward(batch)
+        out = h.forward(batch)
+        h.close()
+        assert float(np.abs(out - ref).max() / np.abs(ref).max()) <= 1e-4, paper
+
+
+@pytest.mark.parametrize("force", ["64,64,1,1", "64,32,2,1", "32,32,4,1", "64,64,1,5", "64,32,2,2", "32,32,4,3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_split"])
+def test_every_tile_shape_on_every_layer(weights, oracle_net, monkeypatch, force, prec):
+    """The launch plan picks a tile shape per layer (64x64, 64x32 x 2 K groups, 32x32 x 4 K groups, 5-way split-K); here
+    every shape is FORCED onto every layer that admits it (VNECT_FORCE_TILE = BM,BN,KG,ks), so each kernel variant --
+    including K groups combined with cross-workgroup slabs -- sees 1x1, 3x3, strided, transposed and 7x7 layers, S = 2."""
+    import oracle
+    from tests import helpers
+    scales = [1.0, 0.7]
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(77, smooth=True), scales)
+    ref = oracle_net.forward(batch)
+    monkeypatch.setenv("VNECT_FORCE_TILE", force)
+    monkeypatch.setenv("VNECT_NO_STEM", "1")   # conv1 as a launch of its own (the fused stem has ONE shape; its parity test is below)
+    h = _handle(scales, weights, precision={"bf16": _native().BF16, "fp32_split": _native().FP32_SPLIT}.get(prec, _native().FP32))
+    shapes = {(L["tile_m"], L["tile_n"], L["split_k"]) for L in h.layers() if L["M"]}
+    out = h.forward(batch)
+    again = h.forward(batch)
+    h.close()
+    bm, bn, kg, ks = (int(x) for x in force.split(","))
+    assert (bm, bn) in {(a, b) for a, b, _ in shapes}, shapes  # the forced shape is really in the plan
+    err = float(np.abs(out - ref).max() / np.abs(ref).max())
+    print(force, prec, "rel err %.3g" % err, sorted(shapes))
+    assert err <= (3e-2 if prec == "bf16" else 1e-4)   # the split-product path is held to the fp32 gate
+    assert np.array_equal(out, again)  # K-group and slab sums run in a fixed order

@@ -8,9 +8,10 @@ estimator per video lives in a process of its own (run_estimator_ps.py:120-129).
   instead of loading /opt/rocm's second build of the same SONAME;
 * the driver-shaped command `bench.py --pyramid --scales 1.0 --gpus 1` runs PyramidJob + ncclCommInitRank + one ncclAllGather per
   frame + the timed loop + the profile in one process under backend "nccl";
-* `bench.py --gpus 2` on a box with one device fails at once, non-zero, naming the missing device.
+* `bench.py --gpus N` on a box with N - 1 devices fails at once, non-zero, naming the missing device.
 
-What one GPU canNOT prove is listed in DESIGN.md section 6: RCCL with 3 ranks, cross-device visibility of the p2p exchange's flags.
+What one GPU canNOT prove is listed in DESIGN.md section 6 (RCCL with 3 ranks, cross-device visibility of the p2p exchange's flags);
+the tests that prove it on the first multi-GPU box are tests/test_gpu_multigpu.py (they skip on one device).
 """
 import json
 import os
@@ -132,23 +133,24 @@ def test_bench_pyramid_one_rank_under_nccl():
     assert 500 < d["value"] < 5000 and d["roofline"]["launches_per_frame"] >= 30 and 0.1 < d["roofline"]["frac"] < 1.0
 
 
-def test_bench_gpus_2_on_a_one_gpu_box_fails_fast():
-    """`python bench.py --gpus 2` (the driver's command shape) where only one device exists: non-zero exit within seconds, the
-    message names the missing device; nothing is left waiting in a rendezvous.  Also under a launcher's environment (a rank whose
-    LOCAL_RANK has no device)."""
+def test_bench_more_ranks_than_devices_fails_fast():
+    """`python bench.py --gpus N` (the driver's command shape) where only N - 1 devices exist -- `--gpus 2` on a one-GPU box, `--gpus 9`
+    on an 8-GPU node: non-zero exit within seconds, the message names the missing device; nothing is left waiting in a rendezvous.
+    Also under a launcher's environment (a rank whose LOCAL_RANK has no device).  Runs on every box (round 4 skipped it where a
+    second device exists; the N > 1 parity tests proper are tests/test_gpu_multigpu.py)."""
     import torch
-    if torch.cuda.device_count() >= 2:
-        pytest.skip("this box has the second device")
+    have = torch.cuda.device_count()
+    n = have + 1
     t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"], env=_clean_env(),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"], env=_clean_env(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     dt = time.time() - t0
-    assert r.returncode != 0 and "HIP device 1 is missing" in r.stderr and "exposes 1" in r.stderr, (r.returncode, r.stderr[-1500:])
+    assert r.returncode != 0 and "HIP device %d is missing" % have in r.stderr and "exposes %d" % have in r.stderr, (r.returncode, r.stderr[-1500:])
     assert not r.stdout.strip()
     assert dt < 240, dt                             # one torch import in a throw-away child (minutes only on a box that has never imported torch), no rendezvous time-out
     t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
-                       env=_clean_env(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
+                       env=_clean_env(RANK=str(have), LOCAL_RANK=str(have), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-    assert r.returncode != 0 and "needs HIP device 1" in r.stderr, (r.returncode, r.stderr[-1500:])
+    assert r.returncode != 0 and "needs HIP device %d" % have in r.stderr, (r.returncode, r.stderr[-1500:])
     assert time.time() - t0 < 240

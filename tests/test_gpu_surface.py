@@ -443,6 +443,71 @@ def test_warm_start_leaves_a_fresh_handle(weights):
         assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
 
 
+def test_warm_start_failure_injection(weights, monkeypatch):
+    """What a failure INSIDE the warm start means for vnect_finalize (advisor, round 4): a launch / device error on the plan the handle
+    will run for every frame (VNECT_PRIME_INJECT=hip) fails vnect_finalize with VNECT_E_HIP and its reason; a benign refusal of the
+    grey frame (=state) is skipped with a note in vnect_last_error, the handle is finalized and returns exactly what an unprimed
+    handle returns.  Either way nothing is left in flight and the filter banks are fresh."""
+    from vnect_amd import _native
+    from tests import helpers
+    frame = helpers.synth_frame(9200, smooth=True)
+    monkeypatch.setenv("VNECT_PRIME_INJECT", "hip")
+    h = _native.Handle([1.0], num_frame_slots=2)
+    h.set_weights(weights)
+    with pytest.raises(_native.VnectError) as e:
+        h.finalize()
+    assert e.value.code == _native.E_HIP and "warm start failed" in str(e.value) and "injected warm-start failure (hip)" in str(e.value)
+    h.close()
+    monkeypatch.setenv("VNECT_PRIME_INJECT", "state")
+    h = _native.Handle([1.0], num_frame_slots=2)
+    h.set_weights(weights)
+    h.finalize()                                   # succeeds; the note says what was skipped and why
+    note = _native.lib().vnect_last_error(h._h).decode()
+    assert "warm start skipped" in note and "injected warm-start failure (state)" in note
+    a = [h.infer(frame, T0 + k / 30, T0 + k / 30 + 0.001) for k in range(2)]
+    h.close()
+    monkeypatch.delenv("VNECT_PRIME_INJECT")
+    monkeypatch.setenv("VNECT_PRIME_FRAMES", "0")
+    h = _native.Handle([1.0], num_frame_slots=2)
+    h.set_weights(weights)
+    h.finalize()
+    b = [h.infer(frame, T0 + k / 30, T0 + k / 30 + 0.001) for k in range(2)]
+    h.close()
+    for (a2, a3), (b2, b3) in zip(a, b):
+        assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+
+
+def test_pinned_frame_buffer_equals_pageable_frames(weights):
+    """vnect_frame_buffer (ABI v5): frames captured into the handle's pinned buffers -- whole, or as the strided crops the tracking loop
+    cuts (run_estimator_ps.py:88) -- give bit for bit what the same pixels give from pageable numpy memory (the CPU-staged path), on one
+    filter chain each.  Also: a pageable frame LARGER than anything staged so far grows the internal staging buffer without moving the
+    caller's buffers."""
+    from vnect_amd import VNectEstimator
+    from tests import helpers
+    big = helpers.synth_frame(9300, 480, 640, smooth=True)
+    a = VNectEstimator(scales=[1.0, 0.8], weights=weights, verbose=False)
+    b = VNectEstimator(scales=[1.0, 0.8], weights=weights, verbose=False)
+    buf = [a.frame_buffer(480, 640, i) for i in range(2)]
+    addr = [x.ctypes.data for x in buf]
+    assert buf[0].shape == (480, 640, 3) and buf[0].dtype == np.uint8 and addr[0] != addr[1]
+    crops = [(0, 0, 640, 480), (100, 40, 368, 368), (3, 7, 301, 255), (272, 112, 368, 368)]
+    for k, (x, y, w, h) in enumerate(crops):
+        frame = helpers.synth_frame(9301 + k, 480, 640, smooth=True)
+        buf[k % 2][...] = frame                                           # "capture"
+        t = (T0 + k / 30, T0 + k / 30 + 0.001)
+        p2, p3 = a(buf[k % 2][y:y + h, x:x + w, :], timestamp=t)          # a view INTO the pinned buffer: no CPU copy
+        q2, q3 = b(frame[y:y + h, x:x + w, :], timestamp=t)               # pageable: staged by the CPU
+        assert np.array_equal(p2, q2) and np.array_equal(p3, q3), (k, x, y, w, h)
+    t = (T0 + 1, T0 + 1.001)
+    p2, p3 = a(np.ascontiguousarray(big), timestamp=t)                      # pageable on the handle that owns capture buffers
+    q2, q3 = b(big, timestamp=t)
+    assert np.array_equal(p2, q2) and np.array_equal(p3, q3)
+    assert [a.frame_buffer(480, 640, i).ctypes.data for i in range(2)] == addr   # the caller's buffers did not move
+    with pytest.raises(Exception):
+        a.handle.frame_buffer(2, 10, 10)
+    a.close(), b.close()
+
+
 # ------------------------------------------------------------------------------------------ the bench line's contract
 def test_bench_line_contract():
     """`python bench.py` as the driver runs it (N = 1): ONE JSON line on stdout with the contract's keys -- metric / value / unit /

@@ -331,7 +331,8 @@ def test_tile_choice_invariants_over_the_whole_network(hp):
     assert dc(hp.hp_choose_tile96, 3 * 529) == [64, 96, 2, 1] and dc(hp.hp_choose_tile, 3 * 529) == [64, 64, 1, 1]
     assert dc(hp.hp_choose_tile96, 3 * 529, bf16=1) == [64, 64, 1, 1]
     assert dc(hp.hp_choose_tile96, 529) == [64, 32, 2, 1] and dc(hp.hp_choose_tile96, 2 * 529) == [64, 64, 1, 1] and dc(hp.hp_choose_tile96, 4 * 529) == [64, 64, 1, 1]
-    assert dc(hp.hp_choose_tile, 3 * 529, plan=b"res5c_deconv=64,96,2,1") == [64, 96, 2, 1]           # by plan, on the layer it is built for
+    assert dc(hp.hp_choose_tile96, 2 * 529, plan=b"res5c_deconv=64,96,2,1") == [64, 96, 2, 1]         # by plan, where the default would not pick it
+    assert dc(hp.hp_choose_tile, 3 * 529, plan=b"res5c_deconv=64,96,2,1") == [64, 64, 1, 1]           # ... but never where the caller does not admit it (split-product handle, VNECT_NO_DECONV96)
     assert dc(hp.hp_choose_tile96, 3 * 529, plan=b"res5c_deconv=64,64,1,1") == [64, 64, 1, 1]
     hp.hp_choose_tile(1587, 256, 9, 8, 2304, 1, 0, b"res4b_branch2b", b"64,96,2,1", None, out)                 # ... and on no other
     assert list(out) == [64, 32, 2, 1]

@@ -4,7 +4,7 @@ The oracle's conv stack has no reference-held vectors (TF1 cannot run, no weight
 float64 restatement (tests/test_oracle_net.py).  This test adds something neither restatement can fake: weights built so that heat-map j
 must peak ON a blob painted into the frame, to the pixel, after the whole graph of src/vnect_model.py:27-217, the multi-scale merge
 (src/estimator.py:105-129) and extract_2d_joints (src/utils.py:153-175).  The GPU twin (fp32 and bf16, with the margin-conditioned
-bf16 gate) is tests/test_gpu_parity.py::test_bf16_margin_conditioned_joints.
+bf16 gate) is tests/test_gpu_bf16.py::test_bf16_margin_conditioned_joints.
 """
 import numpy as np
 import pytest
@@ -76,7 +76,7 @@ def test_tracking_loop_locks_onto_the_planted_person(planted_net):
     From the whole frame the loop must find them, crop around them by the box rule (:96-107) and follow them: every joint within two
     heat-map cells of its blob in every frame, every crop within 2.5 cells (of the crop it was measured in) + 8 pixels of the box rule applied to the true positions.  (The oracle
     behind the estimator surface; the GPU twin -- fp32 equal to this loop joint for joint, and bf16 -- is
-    tests/test_gpu_parity.py::test_tracking_loop_follows_planted_blobs.)"""
+    tests/test_gpu_end_to_end.py::test_tracking_loop_follows_planted_blobs.)"""
     import oracle
     from tests import planted
     from vnect_amd import runner

@@ -1,4 +1,4 @@
-"""How often does a heat-map of the synthetic-weight net have a REAL maximum -- one bf16 noise cannot move?  (tests/test_gpu_parity.py::
+"""How often does a heat-map of the synthetic-weight net have a REAL maximum -- one bf16 noise cannot move?  (tests/test_gpu_bf16.py::
 test_bf16_margin_conditioned_joints needs such (frame, joint) pairs to exist.)  For a few weight variants and scale sets: the margin of every
 fp32 maximum in units of eps = 3e-2 * max|fp32 maps| (the bf16 map gate), (a) in the x8-upsampled map against the best pixel outside the
 maximum's 8x8 block, (b) in the merged 46x46 map against the best other cell.  Prints counts; writes nothing.

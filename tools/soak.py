@@ -1,6 +1,6 @@
 """Long soak of the product path (tuning / release aid; runs on the GPU box, ~75 s): 20 000 synchronous frames twice -- the two runs must
 agree bit for bit -- and the same 20 000 frames three in flight on three lanes -- must equal the sequential result --, fp32 and bf16.
-tests/test_gpu_parity.py::test_soak_three_lanes_deterministic is the short form (3 000 frames) the suite runs."""
+tests/test_gpu_end_to_end.py::test_soak_three_lanes_deterministic is the short form (3 000 frames) the suite runs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -15,7 +15,7 @@ _lib = None
 
 MAX_SCALES = 8
 OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM, E_TIMEORDER, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_STREAMS = 4
 XCHG_RCCL, XCHG_P2P = 0, 1
 FP32, BF16, FP32_SPLIT = 0, 1, 2
@@ -62,6 +62,7 @@ SYMBOLS = {
     "vnect_preprocess": (C.c_int, [_H, _u8p, C.c_int, C.c_int, C.c_int64, _f32p, _f64p, _i32p, _i32p]),
     "vnect_postprocess": (C.c_int, [_H, _f32p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _f64p, _f32p]),
     "vnect_infer": (C.c_int, [_H, _u8p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, _f64p, _f32p]),
+    "vnect_frame_buffer": (C.c_int, [_H, C.c_int, C.c_int64, C.POINTER(_u8p)]),
     "vnect_upload_frame": (C.c_int, [_H, C.c_int, _u8p, C.c_int, C.c_int, C.c_int64]),
     "vnect_infer_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, _f64p, _f32p]),
     "vnect_submit_resident": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
@@ -205,6 +206,13 @@ class Handle:
         self._ck(lib().vnect_infer(self._h, _ptr(img, _u8p), H, W, img.strides[0], t2d, t3d, _ptr(j2, _f64p),
                                    _ptr(j3, _f32p)))
         return j2, j3
+
+    def frame_buffer(self, index, H, W):
+        """(H, W, 3) uint8 array over the handle's pinned staging buffer `index` (0 / 1): frames captured into it -- or crops of them --
+        go to the device without a CPU copy when passed to infer().  Valid until a larger request for the same index or close()."""
+        p = _u8p()
+        self._ck(lib().vnect_frame_buffer(self._h, index, H * W * 3, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(H, W, 3))
 
     def upload_frame(self, slot, img):
         img = _as_frame(img)

@@ -1446,6 +1446,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 {
     const int n4 = a.Npad >> 2;
     const long long total = a.npix * n4;
+    // vector loads / stores of the shortcut and the output need 4-element pixel strides AND 16-byte (bf16: 8-byte) aligned bases -- checked once
+    // here for both (advisor, round 4: the alignment test used to sit at the store only)
+    const int esz = a.bf16 ? 2 : 4, oesz = (a.bf16 && !a.out_f32) ? 2 : 4;
+    const bool vec_ok = ((a.ldc | a.ldr) & 3) == 0 && (((uintptr_t)a.out) & (4 * oesz - 1)) == 0 && (!a.resid || (((uintptr_t)a.resid) & (4 * esz - 1)) == 0);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long pix = idx / n4;
@@ -1454,7 +1458,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 #pragma unroll
         for (int k = 0; k < 8; k++)  // all slab loads in flight at once
             if (k < a.ksplit) part[k] = *(const f32x4*)(a.ws + ((long long)k * a.slab_pix + pix) * a.Npad + n);
-        const bool whole = n + 3 < a.Nvalid;  // (bias / scale / shift are padded to Npad, the tensors' pixel strides are multiples of 4)
+        const bool whole = vec_ok && n + 3 < a.Nvalid;  // (bias / scale / shift are padded to Npad)
         f32x4 bv = {0.f, 0.f, 0.f, 0.f}, scv = {1.f, 1.f, 1.f, 1.f}, shv = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
         if (whole) {
             bv = *(const f32x4*)(a.bias + n);
@@ -1468,7 +1472,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a)
 #pragma unroll
         for (int k = 1; k < 8; k++)  // summed in slice order: deterministic
             if (k < a.ksplit) s += part[k];
-        if (whole && ((a.ldc | a.ldr) & 3) == 0) {
+        if (whole) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -1657,6 +1661,11 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     return hipGetLastError();
 }
 
+// The three-accumulator shape is an optimisation with a working 64x64 fallback: if a toolchain ever allocates more than 256 registers or
+// spills for it, the library stays usable and the launch plan keeps the transposed conv on 64x64 tiles (runtime.cpp: choose_tile).
+static bool g_deconv96 = false;
+bool conv_deconv96_available() { return g_deconv96; }
+
 template <int BM, int BN, int KG, int NS>
 static hipError_t setup_stream_rest();
 template <int BM, int BN, int KG, int NS>
@@ -1743,7 +1752,9 @@ hipError_t conv_setup()
     if ((e = setup_stream<64, 32, 2, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 128, 1, 5>()) != hipSuccess) return e;
-    if ((e = setup_stream<64, 96, 2, 3>()) != hipSuccess) return e;
+    e = setup_stream<64, 96, 2, 3>();
+    g_deconv96 = e == hipSuccess;
+    if (e != hipSuccess && e != hipErrorLaunchOutOfResources) return e;  // out of registers: deconv96 unavailable, not an error
     return hipSuccess;
 }
 
@@ -1759,7 +1770,7 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
     if (KG == 4 && BM == 32 && BN == 32) return launch_stream<32, 32, 4, 4>(a, st);
     if (KG == 1 && BM == 64 && BN == 64) return launch_stream<64, 64, 1, 5>(a, st);
     if (KG == 1 && BM == 32 && BN == 128) return launch_stream<32, 128, 1, 5>(a, st);
-    if (KG == 2 && BM == 64 && BN == 96) return launch_stream<64, 96, 2, 3>(a, st);  // 3 stages of 40 KiB + 24 KiB of partial sums: one workgroup per CU
+    if (KG == 2 && BM == 64 && BN == 96) return g_deconv96 ? launch_stream<64, 96, 2, 3>(a, st) : hipErrorInvalidValue;  // 3 stages of 40 KiB + 24 KiB of partial sums: one workgroup per CU
     return hipErrorInvalidValue;
 }
 

@@ -393,7 +393,10 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
         int fBM = 0, fBN = 0, fKG = 0, fks = 0;
         if (sscanf(spec, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) != 4 || fks < 1 || fks > 8 || cpt % std::max(fKG, 1) != 0) return;
         if (fBM == 64 && fBN == 96 && fKG == 2) {  // (the three-accumulator shape: where it is built for, never with K slabs)
-            if (deconv96_ok) c.BM = 64, c.BN = 96, c.KG = 2, c.ks = 1;
+            // an override can ask for the shape where the default would not pick it (other tile counts), but never where the caller
+            // says the layer or the handle does not admit it -- a split-product handle, VNECT_NO_DECONV96, a build whose 96-wide
+            // instantiation did not fit the register file (conv.hip: conv_deconv96_available): `allow_deconv96` covers all three
+            if (deconv96_ok && allow_deconv96) c.BM = 64, c.BN = 96, c.KG = 2, c.ks = 1;
             return;
         }
         if (tile_shape_ok(fBM, fBN, fKG)) c.BM = fBM, c.BN = fBN, c.KG = fKG, c.ks = std::max(1, std::min(fks, nch / fKG));

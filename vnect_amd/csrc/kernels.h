@@ -109,6 +109,7 @@ __device__ __forceinline__ void store_wt(V* p, V v) { *p = v; }
 hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st);  // KG: in-workgroup K groups (1, 2, 4)
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
 hipError_t conv_setup();  // one-time function attributes (dynamic LDS size)
+bool conv_deconv96_available();  // after conv_setup: the 64x96x2 three-accumulator instantiations fit the register file
 
 hipError_t launch_pad3to4(const float* in3, void* out4, long long npix, int bf16, hipStream_t st);
 hipError_t launch_strip4to3(const void* in4, float* out3, long long npix, int bf16, hipStream_t st);

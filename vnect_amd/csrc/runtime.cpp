@@ -102,6 +102,12 @@ struct vnect_handle {
     vnect_handle* last_lane = nullptr;  // lane of the most recently submitted frame
     // pre/post
     uint8_t* frames = nullptr;  // num_frame_slots * max_frame_bytes
+    // vnect_infer's way from host memory to slot 0: pinned (page-locked) buffers.  [0], [1] are the caller's capture buffers
+    // (vnect_frame_buffer; they only move when the caller asks for a larger one): a frame that lies inside one of them is copied to the
+    // device straight from there.  Any other pointer is first copied into [2] by the CPU (grown on demand; vnect_infer is synchronous,
+    // so one suffices).  The device copy is asynchronous on the frame's stream: nothing synchronises between it and the frame's first kernel.
+    uint8_t* stage[3] = {};
+    size_t stage_cap[3] = {};
     size_t pre_frame_cap = 0;   // preprocess_only: bytes of the one, growable frame slot
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; long long last_use = -1; };  // last_use: sequence number of the last frame that reads this slot
     std::vector<SlotInfo> slots;
@@ -343,7 +349,7 @@ void choose_tile(Layer& L, long long npix, bool allow96 = false)
     // (allow96: the transposed conv's three-accumulator shape, fp32 instruction path only -- not on a split-product handle, whose 64x64
     // split-product loop is the faster one for this layer; VNECT_NO_DECONV96=1 restores the 64x64 plan for A/B runs)
     const plan::TileChoice c = plan::choose_tile(L.a.M, L.Nreal, L.a.ntaps, L.a.cpt, L.a.K, L.a.nphase, L.a.bf16 != 0, L.name,
-                                                 getenv("VNECT_FORCE_TILE"), getenv("VNECT_PLAN"), allow96 && !getenv("VNECT_NO_DECONV96"));
+                                                 getenv("VNECT_FORCE_TILE"), getenv("VNECT_PLAN"), allow96 && conv_deconv96_available() && !getenv("VNECT_NO_DECONV96"));
     L.BM = c.BM, L.BN = c.BN, L.KG = c.KG, L.a.ksplit = c.ks;
 }
 
@@ -1452,6 +1458,47 @@ int collect_impl(vnect_handle* h, double* j2, float* j3, int32_t* stream_out = n
     return VNECT_OK;
 }
 
+// pinned staging buffer i with room for `bytes` (grows in 1-MiB steps; a grown buffer moves, so nothing may be in flight)
+int ensure_stage(vnect_handle* h, int i, size_t bytes)
+{
+    if (h->stage_cap[i] >= bytes) return VNECT_OK;
+    HIPCK(h, hipStreamSynchronize(h->st));
+    if (h->stage[i]) HIPCK(h, hipHostFree(h->stage[i]));
+    h->stage[i] = nullptr, h->stage_cap[i] = 0;
+    const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    HIPCK(h, hipHostMalloc((void**)&h->stage[i], cap, hipHostMallocDefault));
+    h->stage_cap[i] = cap;
+    return VNECT_OK;
+}
+
+// vnect_infer: the frame goes to slot `slot` through pinned memory, asynchronously on the handle's stream (the caller runs the frame
+// on that stream next).  VNECT_INFER_SYNC_COPY=1: the round-4 form (a synchronous pageable hipMemcpy2D), for A/B runs.
+int stage_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
+{
+    if (!bgr || slot < 0 || slot >= (int)h->slots.size()) return fail(h, VNECT_E_ARG, "bad frame slot");
+    if (H < 1 || W < 1 || row_stride < (int64_t)W * 3) return fail(h, VNECT_E_ARG, "bad frame geometry");
+    if ((size_t)H * W * 3 > (size_t)h->cfg.max_frame_bytes) return fail(h, VNECT_E_ARG, "frame larger than max_frame_bytes");
+    const size_t row = (size_t)W * 3, span = (size_t)(H - 1) * (size_t)row_stride + row;
+    const uint8_t* src = nullptr;
+    size_t src_stride = (size_t)row_stride;
+    for (int i = 0; i < 2 && !src; i++)  // already in pinned memory (a crop of a frame the caller captured into vnect_frame_buffer)?
+        if (h->stage[i] && bgr >= h->stage[i] && bgr + span <= h->stage[i] + h->stage_cap[i]) src = bgr;
+    if (!src) {
+        const int i = 2;
+        int rc = ensure_stage(h, i, (size_t)H * row);
+        if (rc) return rc;
+        if ((size_t)row_stride == row) memcpy(h->stage[i], bgr, (size_t)H * row);
+        else
+            for (int y = 0; y < H; y++) memcpy(h->stage[i] + (size_t)y * row, bgr + (size_t)y * (size_t)row_stride, row);
+        src = h->stage[i], src_stride = row;
+    }
+    uint8_t* dst = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
+    if (src_stride == row) HIPCK(h, hipMemcpyAsync(dst, src, (size_t)H * row, hipMemcpyHostToDevice, h->st));
+    else HIPCK(h, hipMemcpy2DAsync(dst, row, src, src_stride, row, H, hipMemcpyHostToDevice, h->st));
+    h->slots[slot].H = H, h->slots[slot].W = W, h->slots[slot].stride = (long long)row;
+    return VNECT_OK;
+}
+
 int upload_frame_impl(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
 {
     if (!bgr || slot < 0 || slot >= (int)h->slots.size()) return fail(h, VNECT_E_ARG, "bad frame slot");
@@ -1495,7 +1542,14 @@ int prime(vnect_handle* h)
     h->slots[ps].H = BOX, h->slots[ps].W = BOX, h->slots[ps].stride = (long long)BOX * 3;
     int rc = VNECT_OK, ring = 0;
     double t = 1.0;
+    // failure injection for the test of this path (tests/test_gpu_surface.py): VNECT_PRIME_INJECT=hip makes the second grey frame fail
+    // like a launch error, =state like a benign refusal
+    const char* inject = getenv("VNECT_PRIME_INJECT");
     for (int i = 0; i < n_env && !rc; i++, t += 1.0) {
+        if (inject && i == 1) {
+            rc = fail(h, !strcmp(inject, "hip") ? VNECT_E_HIP : VNECT_E_STATE, std::string("injected warm-start failure (") + inject + ")");
+            break;
+        }
         rc = enqueue_frame(h, ps, t, t, &ring);
         if (!rc) rc = collect_impl(h, nullptr, nullptr);
     }
@@ -1504,10 +1558,12 @@ int prime(vnect_handle* h)
         for (int i = 0; i < depth && !rc; i++, t += 1.0) rc = enqueue_frame(h, ps, t, t, &ring);
         for (int i = 0; i < depth && !rc; i++) rc = collect_impl(h, nullptr, nullptr);
     }
-    // A fresh handle's state comes back UNCONDITIONALLY -- the warm start is an optimisation, and the caller of vnect_finalize holds a
-    // finalized handle whatever happened to a grey frame: if one failed, whatever is still in flight is drained and dropped, the
-    // slot is emptied, the filter banks are rebuilt, and the reason is left in vnect_last_error as a note.  A device that is really
-    // broken fails the first real frame with its own error code.
+    // A fresh handle's state comes back UNCONDITIONALLY: whatever is still in flight is drained and dropped, the slot is emptied, the
+    // filter banks are rebuilt.  What the failure means for vnect_finalize depends on its kind (advisor, round 4):
+    //  * VNECT_E_HIP / VNECT_E_INTERNAL / VNECT_E_COMM -- a launch was refused or the device faulted on the launch plan this handle
+    //    will run for every real frame: that is a broken plan or a broken device, and vnect_finalize returns the code with the reason;
+    //  * anything else (a refused argument or state of the grey frame itself) -- the warm start is an optimisation: skipped, noted in
+    //    vnect_last_error, vnect_finalize succeeds.
     const std::string why = rc ? h->err : std::string();
     if (rc) {
         (void)hipStreamSynchronize(h->st);
@@ -1516,12 +1572,21 @@ int prime(vnect_handle* h)
         h->seq_collect = h->seq_submit;
     }
     h->slots[ps] = vnect_handle::SlotInfo();
-    const int rf = reset_filters_impl(h);
+    const int rf = reset_filters_impl(h);  // (sets h->err itself when it fails)
     for (int s = 0; s < VNECT_MAX_STREAMS; s++) h->stream_seq[s] = -1, h->stream_lane[s] = nullptr;
     h->fp_dev_valid = false;  // (the next frame uploads its own geometry)
     for (vnect_handle* tw : h->twins) tw->fp_dev_valid = false;
+    const bool serious = rc == VNECT_E_HIP || rc == VNECT_E_INTERNAL || rc == VNECT_E_COMM;
+    if (rf) {  // the filter banks could not be rebuilt: the handle must not be used; keep both reasons
+        if (rc) h->err += "; behind a failed warm start: " + why;
+        return rf;
+    }
+    if (serious) {
+        h->err = "warm start failed -- the launch plan or the device is broken: " + why;
+        return rc;
+    }
     if (rc) h->err = "warm start skipped (not an error of vnect_finalize): " + why;
-    return rf;  // only a failure to rebuild the filter banks leaves the handle in a state a caller must not use
+    return VNECT_OK;
 }
 
 }  // namespace
@@ -1673,6 +1738,8 @@ void vnect_destroy(vnect_handle* h)
     for (int r = 0; r < VNECT_MAX_SCALES; r++)
         if (h->xopened[r] && h->xpeer[r]) hipIpcCloseMemHandle(h->xpeer[r]);
     if (h->h_xstatus) hipHostFree(h->h_xstatus);
+    for (int i = 0; i < 3; i++)
+        if (h->stage[i]) hipHostFree(h->stage[i]);
     if (h->h_filt) hipHostFree(h->h_filt);
     if (h->h_prof) hipHostFree(h->h_prof);
     if (h->h_prof_end) hipHostFree(h->h_prof_end);
@@ -1835,6 +1902,21 @@ int vnect_postprocess(vnect_handle* h, const float* maps, double t2d, double t3d
     });
 }
 
+int vnect_frame_buffer(vnect_handle* h, int index, int64_t min_bytes, uint8_t** ptr_out)
+{
+    return guarded(&h, [&]() -> int {
+        if (!h || !ptr_out || index < 0 || index > 1 || min_bytes < 1) return h ? fail(h, VNECT_E_ARG, "vnect_frame_buffer: bad argument") : VNECT_E_ARG;
+        if (h->pre_only) return fail(h, VNECT_E_STATE, "vnect_frame_buffer on a preprocess_only handle");
+        if (min_bytes > (int64_t)h->cfg.max_frame_bytes) return fail(h, VNECT_E_ARG, "vnect_frame_buffer: larger than max_frame_bytes");
+        if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
+        HIPCK(h, hipSetDevice(h->cfg.device));
+        int rc = ensure_stage(h, index, (size_t)min_bytes);
+        if (rc) return rc;
+        *ptr_out = h->stage[index];
+        return VNECT_OK;
+    });
+}
+
 int vnect_upload_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
 {
     return guarded(&h, [&]() -> int {
@@ -1916,7 +1998,9 @@ int vnect_infer(vnect_handle* h, const uint8_t* bgr, int H, int W, int64_t row_s
         if (!h->finalized) return fail(h, VNECT_E_STATE, "vnect_infer before vnect_finalize");
         if (h->seq_submit != h->seq_collect) return fail(h, VNECT_E_STATE, "frames in flight");
         HIPCK(h, hipSetDevice(h->cfg.device));
-        int rc = upload_frame_impl(h, 0, bgr, H, W, row_stride);
+        // nothing is in flight, so the frame will run on the first lane's stream (enqueue_frame), the stream stage_frame copies on
+        static const bool sync_copy = getenv("VNECT_INFER_SYNC_COPY") != nullptr;
+        int rc = sync_copy ? upload_frame_impl(h, 0, bgr, H, W, row_stride) : stage_frame(h, 0, bgr, H, W, row_stride);
         if (rc) return rc;
         return vnect_infer_resident(h, 0, t2d, t3d, j2, j3);
     });

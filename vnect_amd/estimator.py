@@ -168,6 +168,12 @@ class VNectEstimator:
         """(joints_2d, joints_3d) of the oldest frame in flight."""
         return self._h.collect()
 
+    def frame_buffer(self, height, width, index=0):
+        """Additive: a (height, width, 3) uint8 array in PINNED host memory (two exist, ``index`` 0 / 1).  Capture into it
+        (``cap.read(buf)``, ``buf[...] = frame``) and pass it -- or a crop of it, as the tracking loop does -- to the estimator: the
+        frame then crosses PCIe without the CPU copy a pageable array needs first."""
+        return self._h.frame_buffer(index, height, width)
+
     def reset(self):
         self._h.reset_filters()
 
