@@ -150,6 +150,8 @@ from vnect_amd import _native
 from vnect_amd.weights import synthetic_weights
 from tests import helpers
 rank, dev, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+def note(msg):
+    sys.stderr.write("[missing-peer rank %%d] %%s\n" %% (rank, msg)); sys.stderr.flush()
 h = _native.Handle([1.0, 0.7], device=dev, pyramid=(rank, 2), exchange=_native.XCHG_P2P)
 h.set_weights(synthetic_weights())
 h.finalize()
@@ -159,13 +161,21 @@ t0 = time.time()
 while not all(os.path.exists(os.path.join(d, "blob%%d" %% r)) for r in range(2)):
     assert time.time() - t0 < 300
     time.sleep(0.05)
+note("blobs there")
 h.p2p_init(rank, 2, [open(os.path.join(d, "blob%%d" %% r), "rb").read() for r in range(2)])
+note("p2p_init done")
+open(os.path.join(d, "ready%%d" %% rank), "w").write("x")
+t0 = time.time()
+while not all(os.path.exists(os.path.join(d, "ready%%d" %% r)) for r in range(2)):   # nobody closes a block a peer is still mapping
+    assert time.time() - t0 < 300
+    time.sleep(0.05)
 if rank == 0:
     try:
         h.infer(helpers.synth_frame(3), 1.7e9, 1.7e9)     # rank 1 never submits this frame
         print("RESULT no-error", flush=True)
     except _native.VnectError as e:
         print("RESULT code %%d" %% e.code, flush=True)
+    note("frame returned")
     open(os.path.join(d, "done"), "w").write("x")
 else:
     t0 = time.time()
@@ -173,7 +183,9 @@ else:
         assert time.time() - t0 < 600
         time.sleep(0.05)
     print("RESULT idle", flush=True)
+note("closing")
 h.close()
+note("closed")
 """
 
 
@@ -181,14 +193,23 @@ def _missing_peer(tmp_path, devices):
     script = tmp_path / "p2p_missing_peer.py"
     script.write_text(P2P_MISSING_PEER % ROOT)
     env = _clean_env(VNECT_XCHG_SPINS="20000")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    logs = [open(os.path.join(ROOT, "gpurun_out", "missing_peer_rank%d.log" % r), "w") for r in range(2)]   # a hang leaves its trace here
     procs = [subprocess.Popen([sys.executable, str(script), str(r), str(devices[r]), str(tmp_path)], env=env, stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+                              stderr=logs[r], text=True) for r in range(2)]
     t0 = time.time()
     res = []
-    for p in procs:
-        o, e = p.communicate(timeout=900)
-        assert p.returncode == 0, e[-3000:]
-        res.append([ln for ln in o.splitlines() if ln.startswith("RESULT")][-1])
+    try:
+        for r, p in enumerate(procs):
+            o, _ = p.communicate(timeout=150)
+            assert p.returncode == 0, open(logs[r].name).read()[-3000:]
+            res.append([ln for ln in o.splitlines() if ln.startswith("RESULT")][-1])
+    finally:
+        for p in procs:          # the exact processes this test started
+            if p.poll() is None:
+                p.kill()
+        for f in logs:
+            f.close()
     from vnect_amd import _native
     assert res[0] == "RESULT code %d" % _native.E_COMM and res[1] == "RESULT idle", res
     return time.time() - t0

@@ -130,6 +130,9 @@ struct FrameDyn {     // what does change every frame: passed to the two kernels
 
 hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
+// vnect_infer: H rows of `row` bytes from device-mapped pinned host memory (`stride` bytes apart) into a resident frame slot, as a kernel
+hipError_t launch_frame_copy(const uint8_t* src_dev, uint8_t* dst, int H, int row, long long stride, hipStream_t st);
+
 // ---- the stem as one launch (stem.hip): [gen_input_batch ->] conv1 + ReLU -> 3x3 / stride-2 max-pool on spatial tiles -------------
 struct StemArgs {
     const void* batch;     // (S,368,368,4) NHWC4 batch (fp32 / bf16), or nullptr with from_frame

@@ -38,6 +38,42 @@ hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// vnect_infer's host-to-device copy as a KERNEL on the frame's own stream: rows of `row` bytes from device-mapped PINNED host memory
+// (src, stride bytes apart) to the resident frame slot (dst, rows packed).  hipMemcpyAsync of the same 406 KB costs ~21 us of a
+// synchronous frame on this runtime (the copy engine and its hand-over to the compute queue); a kernel in front of the stem costs the
+// PCIe transfer (~8 us) and one dependent boundary.  Three forms, chosen on the host: whole 16-byte units of one contiguous run, dwords
+// per row, bytes per row.
+__global__ __launch_bounds__(256) void frame_copy_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int row, long long stride, int form)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (form == 0) {          // contiguous, both ends 16-byte aligned: the frame as a run of 16-byte units (+ a byte tail)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const long long n = (long long)H * row, n16 = n >> 4;
+        if (i < n16) ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
+        if (i < (n & 15)) dst[(n16 << 4) + i] = src[(n16 << 4) + i];
+    } else if (form == 1) {   // dword-aligned rows
+        const int rw = row >> 2;
+        const long long y = i / rw;
+        const int x = (int)(i - y * rw);
+        if (y < H) ((unsigned*)(dst + y * row))[x] = ((const unsigned*)(src + y * stride))[x];
+    } else {
+        const long long y = i / row;
+        const int x = (int)(i - y * row);
+        if (y < H) dst[y * row + x] = src[y * stride + x];
+    }
+}
+hipError_t launch_frame_copy(const uint8_t* src_dev, uint8_t* dst, int H, int row, long long stride, hipStream_t st)
+{
+    const long long n = (long long)H * row;
+    int form = 2;
+    long long threads = n;
+    if (stride == row && (((uintptr_t)src_dev | (uintptr_t)dst) & 15) == 0) form = 0, threads = (n >> 4) > 16 ? (n >> 4) : 16;
+    else if (((row | stride) & 3) == 0 && (((uintptr_t)src_dev | (uintptr_t)dst) & 3) == 0) form = 1, threads = n >> 2;
+    hipLaunchKernelGGL(frame_copy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, src_dev, dst, H, row, stride, form);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // estimator.py:105-129: one cell of a merged map,
 //   avg_q[r][c][j] = (1/S) * sum_i crop(cv2.resize(map_i_q, fx=fy=1/s_i))[r][c][j]   (f32 interpolation, f64 sum)
 // evaluated on demand: the four 46x46x21 f64 averages of the reference are never materialised.  Round 3: the taps and weights are

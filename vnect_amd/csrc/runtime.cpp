@@ -107,6 +107,7 @@ struct vnect_handle {
     // device straight from there.  Any other pointer is first copied into [2] by the CPU (grown on demand; vnect_infer is synchronous,
     // so one suffices).  The device copy is asynchronous on the frame's stream: nothing synchronises between it and the frame's first kernel.
     uint8_t* stage[3] = {};
+    uint8_t* stage_dev[3] = {};  // the same buffers as the device addresses them (hipHostMallocMapped)
     size_t stage_cap[3] = {};
     size_t pre_frame_cap = 0;   // preprocess_only: bytes of the one, growable frame slot
     struct SlotInfo { int H = 0, W = 0; long long stride = 0; long long last_use = -1; };  // last_use: sequence number of the last frame that reads this slot
@@ -1466,23 +1467,25 @@ int ensure_stage(vnect_handle* h, int i, size_t bytes)
     if (h->stage[i]) HIPCK(h, hipHostFree(h->stage[i]));
     h->stage[i] = nullptr, h->stage_cap[i] = 0;
     const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    HIPCK(h, hipHostMalloc((void**)&h->stage[i], cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void**)&h->stage[i], cap, hipHostMallocMapped));
+    HIPCK(h, hipHostGetDevicePointer((void**)&h->stage_dev[i], h->stage[i], 0));
     h->stage_cap[i] = cap;
     return VNECT_OK;
 }
 
 // vnect_infer: the frame goes to slot `slot` through pinned memory, asynchronously on the handle's stream (the caller runs the frame
-// on that stream next).  VNECT_INFER_SYNC_COPY=1: the round-4 form (a synchronous pageable hipMemcpy2D), for A/B runs.
+// on that stream next).  The copy is a kernel reading the pinned buffer over PCIe (post.hip: frame_copy_kernel; VNECT_INFER_DMA=1: the
+// copy engine instead, hipMemcpyAsync).  VNECT_INFER_SYNC_COPY=1: the round-4 form (a synchronous pageable hipMemcpy2D), for A/B runs.
 int stage_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int64_t row_stride)
 {
     if (!bgr || slot < 0 || slot >= (int)h->slots.size()) return fail(h, VNECT_E_ARG, "bad frame slot");
     if (H < 1 || W < 1 || row_stride < (int64_t)W * 3) return fail(h, VNECT_E_ARG, "bad frame geometry");
     if ((size_t)H * W * 3 > (size_t)h->cfg.max_frame_bytes) return fail(h, VNECT_E_ARG, "frame larger than max_frame_bytes");
     const size_t row = (size_t)W * 3, span = (size_t)(H - 1) * (size_t)row_stride + row;
-    const uint8_t* src = nullptr;
+    const uint8_t *src = nullptr, *src_dev = nullptr;
     size_t src_stride = (size_t)row_stride;
     for (int i = 0; i < 2 && !src; i++)  // already in pinned memory (a crop of a frame the caller captured into vnect_frame_buffer)?
-        if (h->stage[i] && bgr >= h->stage[i] && bgr + span <= h->stage[i] + h->stage_cap[i]) src = bgr;
+        if (h->stage[i] && bgr >= h->stage[i] && bgr + span <= h->stage[i] + h->stage_cap[i]) src = bgr, src_dev = h->stage_dev[i] + (bgr - h->stage[i]);
     if (!src) {
         const int i = 2;
         int rc = ensure_stage(h, i, (size_t)H * row);
@@ -1490,10 +1493,12 @@ int stage_frame(vnect_handle* h, int slot, const uint8_t* bgr, int H, int W, int
         if ((size_t)row_stride == row) memcpy(h->stage[i], bgr, (size_t)H * row);
         else
             for (int y = 0; y < H; y++) memcpy(h->stage[i] + (size_t)y * row, bgr + (size_t)y * (size_t)row_stride, row);
-        src = h->stage[i], src_stride = row;
+        src = h->stage[i], src_dev = h->stage_dev[i], src_stride = row;
     }
     uint8_t* dst = h->frames + (size_t)slot * h->cfg.max_frame_bytes;
-    if (src_stride == row) HIPCK(h, hipMemcpyAsync(dst, src, (size_t)H * row, hipMemcpyHostToDevice, h->st));
+    static const bool dma = getenv("VNECT_INFER_DMA") != nullptr;
+    if (!dma) HIPCK(h, launch_frame_copy(src_dev, dst, H, (int)row, (long long)src_stride, h->st));
+    else if (src_stride == row) HIPCK(h, hipMemcpyAsync(dst, src, (size_t)H * row, hipMemcpyHostToDevice, h->st));
     else HIPCK(h, hipMemcpy2DAsync(dst, row, src, src_stride, row, H, hipMemcpyHostToDevice, h->st));
     h->slots[slot].H = H, h->slots[slot].W = W, h->slots[slot].stride = (long long)row;
     return VNECT_OK;
