@@ -550,10 +550,16 @@ __device__ __forceinline__ void chain_narrow(const ConvArgs& a, const float* sme
 // split offline (hostplan.h: pack_split3) and land as three 64-byte planes per row and chunk -- 20 KiB per stage instead of 16, so the
 // ring has 4 stages in the same 80 KB.  Results differ from the fp32 instruction's in the last bits only (summation order, the dropped
 // terms); the parity gates are the fp32 path's.
-template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false, bool X3 = false>
+// ONE (round 5): the launch has exactly one work item per workgroup and no cross-workgroup K split (grid == items, ksplit == 1: 35 of the 38
+// conv launches of a three-scale frame; the launcher checks) -- the streaming machinery (item count, stride, the next item's set-up inside
+// the issue path, K slices) is compiled OUT of such a launch's kernel.  A launch's cold start is ~750 one-off instructions in front of the
+// first DMA, issued at one per ~4 cycles by a single wave (profiles/r04_phase_producer_start.txt): what is not there is not issued.  Every
+// fused form (FUSE != 0) is a one-item launch by construction.
+template <int BM, int BN, int KG, int NS, bool BF, int PROF, int FUSE = 0, bool SPAN = false, bool X3 = false, bool ONE = false>
 __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_stream_kernel(const ConvArgs a)
 {
     constexpr bool TAIL = FUSE == 1 || FUSE == 3, BONE = FUSE == 2, CHAIN = FUSE == 3;  // 3: the wide tail with a chain GEMM behind it
+    constexpr bool SINGLE = ONE || FUSE != 0;  // one item per workgroup, ksplit == 1
     static_assert(!SPAN || (BM == 64 && BN == 64 && KG == 1 && !BF && FUSE == 0), "span mode is conv1's fp32 form");
     // NACC (round 4): 32-column blocks per consumer wave.  64 x 96 x 2 -- two K groups x two row blocks, every wave THREE accumulators that share
     // its A fragments -- exists for the transposed conv in fp32: 300 tiles of 64 x 64 on 256 CUs are two rounds for 44 of them, 200 tiles
@@ -620,10 +626,10 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         const int nwx = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
         it_first = lo + l, it_stride = nwx;
         // one item per workgroup (grid == items, most layers): skip the integer division (~35 cold instructions)
-        if (h.items == nwg) my_n = 1;
+        if (SINGLE || h.items == nwg) my_n = 1;
         else my_n = __builtin_amdgcn_readfirstlane(l < cnt ? (cnt - l + nwx - 1) / nwx : 0);
     }
-    if (my_n == 0) return;  // whole workgroup: no barrier has been issued yet
+    if (!SINGLE && my_n == 0) return;  // whole workgroup: no barrier has been issued yet
     const int nch = h.ntaps * h.cpt;  // K steps per tile (the launcher passes cpt in steps of KG chunks)
     struct Item {
         int m0, n0, phase, ks, c0, cnt;
@@ -637,9 +643,10 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         const int zz = __builtin_amdgcn_readfirstlane(fdiv(t2, h.mg_tm, h.tiles_m));
         const int tile_m = t2 - zz * h.tiles_m;
         Item it;
-        it.phase = __builtin_amdgcn_readfirstlane(fdiv(zz, h.mg_ks, h.ksplit)), it.ks = zz - it.phase * h.ksplit;
+        if constexpr (SINGLE) it.phase = zz, it.ks = 0;
+        else it.phase = __builtin_amdgcn_readfirstlane(fdiv(zz, h.mg_ks, h.ksplit)), it.ks = zz - it.phase * h.ksplit;
         it.m0 = tile_m * BM, it.n0 = tile_n * BN;
-        if (h.ksplit == 1) {
+        if (SINGLE || h.ksplit == 1) {
             it.c0 = 0, it.cnt = nch;
         } else {  // K slice ks of ksplit: [nch*ks/ksplit, nch*(ks+1)/ksplit)
             it.c0 = (nch * it.ks) / h.ksplit;
@@ -660,7 +667,8 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         return g;
     };
     int G = 0;  // chunks in this workgroup's stream
-    if (h.ksplit == 1) G = my_n * nch;
+    if (SINGLE) G = nch;
+    else if (h.ksplit == 1) G = my_n * nch;
     else
         for (int j = 0; j < my_n; j++) G += decode(j).cnt;
     const int pix = a.pixmode;
@@ -800,8 +808,10 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
             }
             rem = __builtin_amdgcn_readfirstlane(rem - 1);
             if (rem == 0) {
-                jn = __builtin_amdgcn_readfirstlane(jn + 1);
-                if (jn < my_n) begin_item(jn);
+                if constexpr (!SINGLE) {  // (a one-item launch has nothing behind its last chunk)
+                    jn = __builtin_amdgcn_readfirstlane(jn + 1);
+                    if (jn < my_n) begin_item(jn);
+                }
             } else {
                 soA += 128 * KG, soB += X3 ? 192 * KG * a.Npad : 128 * KG;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
@@ -1133,7 +1143,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     asm volatile("" : "+s"(c.bias), "+s"(c.scale), "+s"(c.shift), "+s"(c.resid), "+s"(c.out), "+s"(c.out2), "+s"(c.ws), "+s"(c.Nvalid),
                  "+s"(c.Npad), "+s"(c.ldr), "+s"(c.ldc), "+s"(c.ldc2), "+s"(c.split_n), "+s"(c.relu_cols), "+s"(c.out_f32), "+s"(c.os),
                  "+s"(c.OH), "+s"(c.OW), "+s"(c.slab_pix));
-    const bool fused = h.ksplit == 1;
+    const bool fused = SINGLE || h.ksplit == 1;
     const bool direct = (c.os == 1);
     const int col = lane & 31, rhalf = 4 * (lane >> 5);  // C/D map: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     cgfloat* resid = fused && !TAIL ? (cgfloat*)c.resid : nullptr;  // (a tail layer's shortcut belongs to its second GEMM)
@@ -1527,7 +1537,14 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     // profiling twin: start / end stamps only, or (VNECT_PROF_DETAIL=1, tools/phase_table.py) the per-phase stamps too
     static const bool detail = getenv("VNECT_PROF_DETAIL") && atoi(getenv("VNECT_PROF_DETAIL")) != 0;
     const int prof = a.prof ? (detail ? 2 : 1) : 0;
-#define LAUNCH_STREAM(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a)
+    // one item per workgroup and no K slabs: the kernel without the streaming machinery (conv_stream_kernel, ONE)
+    static const bool no_one = getenv("VNECT_NO_ONE") != nullptr;  // A/B runs
+    const bool one = a.items <= maxwg && a.ksplit == 1 && !no_one;
+#define LAUNCH_STREAM(BF, PR)                                                                                                        \
+    do {                                                                                                                             \
+        if (one) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR, 0, false, false, true>), grid, dim3(512), lds, st, a); \
+        else hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR>), grid, dim3(512), lds, st, a);                          \
+    } while (0)
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
         if (a.x3) {  // split-product form (plain, with the tail GEMM or with the bone features behind it); start / end stamps at most
             if (a.bf16 || a.pixmode || a.K % 32) return hipErrorInvalidValue;
@@ -1587,13 +1604,18 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
         if (a.bf16 || a.x3 || a.tail_n > 0 || a.resid || a.out2 || a.ksplit != 1 || a.pixmode || (a.relu_cols & 31)) return hipErrorInvalidValue;
         if (a.bone && (a.items > maxwg || a.Npad != 192 || a.ldc < 212)) return hipErrorInvalidValue;
 #define LAUNCH_96(PR, FU) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, false, PR, FU>), grid, dim3(512), lds, st, a)
+#define LAUNCH_96_ONE(PR) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, false, PR, 0, false, false, true>), grid, dim3(512), lds, st, a)
         if (a.bone) {
             if (prof == 0) LAUNCH_96(0, 2);
             else LAUNCH_96(1, 2);
+        } else if (one) {
+            if (prof == 0) LAUNCH_96_ONE(0);
+            else LAUNCH_96_ONE(1);
         } else {
             if (prof == 0) LAUNCH_96(0, 0);
             else LAUNCH_96(1, 0);
         }
+#undef LAUNCH_96_ONE
 #undef LAUNCH_96
         return hipGetLastError();
     }
@@ -1674,7 +1696,9 @@ static hipError_t setup_stream()
     hipFuncAttributes fa;
     if constexpr (BN == 96) {
         for (const void* f : {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 0>,
-                              (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 2>}) {
+                              (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 2>,
+                              (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 0, false, false, true>,
+                              (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 0, false, false, true>}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());
             if (e != hipSuccess) return e;
             e = hipFuncGetAttributes(&fa, f);
@@ -1693,6 +1717,11 @@ static hipError_t setup_stream_rest()
     std::vector<const void*> fns = {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 0>,
                                     (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 1>,
                                     (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>};
+    const void* twins_one[2] = {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2, 0, false, false, true>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2, 0, false, false, true>};
+    for (const void* f : {(const void*)conv_stream_kernel<BM, BN, KG, NS, false, 0, 0, false, false, true>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 0, 0, false, false, true>,
+                          (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 1, 0, false, false, true>, (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 1, 0, false, false, true>,
+                          twins_one[0], twins_one[1]})
+        fns.push_back(f);
     if constexpr (BM == 64 && BN == 64 && KG == 1) {
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 0, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 0, 1>);
         fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 1>), fns.push_back((const void*)conv_stream_kernel<64, 64, 1, NS, true, 1, 1>);
@@ -1737,7 +1766,8 @@ static hipError_t setup_stream_rest()
         if (e != hipSuccess) return e;
         // the launch plan assumes two workgroups per CU (one for the K-group shapes): refuse a build that needs more registers
         // or scratch (the per-phase tuning twins, PROF = 2, may spill a few bytes)
-        const bool twin = f == (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2> || f == (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2>;
+        const bool twin = f == (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2> || f == (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2> ||
+                          f == twins_one[0] || f == twins_one[1];
         if (fa.numRegs > (KG == 1 && BN <= 64 ? 128 : 256) || (fa.localSizeBytes != 0 && !twin)) return hipErrorLaunchOutOfResources;
     }
     return hipSuccess;
