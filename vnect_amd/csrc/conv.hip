@@ -40,7 +40,9 @@ __device__ __forceinline__ void wait_vm()
 
 // x / d for 0 <= x, x * d < 2^32, with mg = ceil(2^32 / d) (d == 1: mg wraps to 0, handled); one v_mul_hi instead of
 // the ~35-instruction integer division sequence, which sat on every workgroup's critical path before its first load
-__device__ __forceinline__ int fdiv(int x, unsigned mg, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, mg); }
+// (d == 1: mg is 2^32 wrapped to 0, the product's high half is 0 and the mask adds x back -- no branch: the `d == 1 ? x : ...` form
+// compiled to a compare-and-branch around every division of the cold start)
+__device__ __forceinline__ int fdiv(int x, unsigned mg, int d) { return (int)(__umulhi((unsigned)x, mg) + ((unsigned)x & (0u - (unsigned)(d == 1)))); }
 
 // Pointers that went through an SGPR pin (inline asm) lose their address space; accesses through them would be FLAT
 // (counted on vmcnt AND lgkmcnt, so the compiler waits for each store before the next: measured 2.5-5 us per epilogue).
@@ -672,6 +674,23 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     else
         for (int j = 0; j < my_n; j++) G += decode(j).cnt;
     const int pix = a.pixmode;
+    // the producers' own argument group.  A one-item launch (SINGLE) has the registers to fetch it together with the common group above --
+    // ONE scalar-cache round trip in front of the cold start instead of two; the streaming forms pin it inside the producers' branch
+    struct Prod {
+        const float *in, *w;
+        int H, W, Cs, K, stride, tap_bias;
+        unsigned mg_cpt;
+        long long w_phase_stride;
+        unsigned long long dy_pack, dx_pack;
+    };
+    auto load_prod = [&]() __attribute__((always_inline)) {
+        Prod q = {a.in, a.w, a.H, a.W, a.Cs, a.K, a.stride, a.tap_bias, a.mg_cpt, a.w_phase_stride, a.dy_pack, a.dx_pack};
+        asm volatile("" : "+s"(q.in), "+s"(q.w), "+s"(q.H), "+s"(q.W), "+s"(q.Cs), "+s"(q.K), "+s"(q.stride), "+s"(q.tap_bias),
+                     "+s"(q.mg_cpt), "+s"(q.w_phase_stride), "+s"(q.dy_pack), "+s"(q.dx_pack));
+        return q;
+    };
+    Prod p0 = {};
+    if constexpr (SINGLE) p0 = load_prod();
 
     if (producer) {
         // ---- producer waves: LDS-DMA issue NS-1 chunks ahead of the consumers, across item boundaries -------
@@ -683,15 +702,8 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         // hardware fetches nothing and writes zeros.  Negative tap offsets are folded into the descriptor's base
         // (in - tap_bias), so the scalar offset is >= 0 (runtime.cpp).
         __builtin_amdgcn_s_setprio(3);
-        struct Prod {
-            const float *in, *w;
-            int H, W, Cs, K, stride, tap_bias;
-            unsigned mg_cpt;
-            long long w_phase_stride;
-            unsigned long long dy_pack, dx_pack;
-        } p = {a.in, a.w, a.H, a.W, a.Cs, a.K, a.stride, a.tap_bias, a.mg_cpt, a.w_phase_stride, a.dy_pack, a.dx_pack};
-        asm volatile("" : "+s"(p.in), "+s"(p.w), "+s"(p.H), "+s"(p.W), "+s"(p.Cs), "+s"(p.K), "+s"(p.stride), "+s"(p.tap_bias),
-                     "+s"(p.mg_cpt), "+s"(p.w_phase_stride), "+s"(p.dy_pack), "+s"(p.dx_pack));
+        Prod p = p0;
+        if constexpr (!SINGLE) p = load_prod();
         // tap entry e = phase*ntaps + tap: (dy, dx) from the packed table, byte offset from the lane's input pixel
         auto tap_dy = [&](int e) __attribute__((always_inline)) { return (int)((p.dy_pack >> (4 * e)) & 15) - 8; };
         auto tap_dx = [&](int e) __attribute__((always_inline)) { return (int)((p.dx_pack >> (4 * e)) & 15) - 8; };
@@ -708,8 +720,9 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
 #pragma unroll
             for (int i = 0; i < ARB; i++) a_cur[i] = a_vo[i] | ((~(a_mask[i] >> t) & 1u) << 31);  // bit 31 set = out of bounds (a select here becomes a divergent branch)
         };
-        auto begin_item = [&](int j) __attribute__((always_inline)) {
-            const Item it = decode(j);
+        // an item's set-up in two halves: the weight side needs the item's column block and phase only, the activation side the per-lane
+        // pixel decode and tap masks.  A one-item launch requests its first two chunks' WEIGHTS between the two (see the start-up below).
+        auto item_A = [&](const Item& it) __attribute__((always_inline)) {
             tb = __builtin_amdgcn_readfirstlane(it.phase * h.ntaps);
             if constexpr (SPAN) {
                 // lane -> pixel slot 64 wave + lane of the tile's run(s); slots behind the runs (and all of wave 3) land zeros
@@ -733,30 +746,38 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
             }
 #pragma unroll
             for (int i = 0; i < (SPAN ? 0 : ARB); i++) {
-                const int m = it.m0 + srow + 32 * i;
-                a_vo[i] = 0, a_mask[i] = 0;
-                if (m < h.M) {
-                    const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
-                    const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
-                    // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
-                    const int iy = oy * p.stride + (pix && BF ? unit >> 2 : 0);
-                    const int ix = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
-                    a_vo[i] = (unsigned)(((s * p.H + iy) * p.W + ix) * p.Cs * ESZ + (pix ? 0 : unit * 16));
-                    // bit t2: tap t2 reads inside the image.  1x1 and 3x3 (pad 1) grids in closed form; any other tap
-                    // table (7x7 rows of conv1, the transposed conv's phases) by walking it
-                    if (a.tapgrid == 1) {
-                        a_mask[i] = 1u;
-                    } else if (a.tapgrid == 3) {
-                        const unsigned vx = (ix >= 1 ? 1u : 0u) | 2u | (ix + 1 < p.W ? 4u : 0u);
-                        a_mask[i] = (iy >= 1 ? vx : 0u) | (vx << 3) | (iy + 1 < p.H ? vx << 6 : 0u);
-                    } else {
-                        for (int t2 = 0; t2 < h.ntaps; t2++) {
-                            const int y = iy + tap_dy(tb + t2), x = ix + tap_dx(tb + t2);
-                            a_mask[i] |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
-                        }
+                // Written without branches for the 1x1 and 3x3 grids (every layer but conv1 and the transposed conv): a row past M decodes
+                // pixel 0 and gets an empty mask (all its taps out of bounds), the grid is chosen by a select.  With `if (m < M)` and an
+                // if-chain over the grids the compiler emitted two exec-masked blocks one after the other, four taken branches each --
+                // on the one cold pass that stands between a launch and its first DMA.
+                const int mraw = it.m0 + srow + 32 * i;
+                const bool live = mraw < h.M;
+                const int m = live ? mraw : 0;
+                const int t = fdiv(m, h.mg_wo, h.Wo), ox = m - t * h.Wo;
+                const int s = fdiv(t, h.mg_ho, h.Ho), oy = t - s * h.Ho;
+                // conv1 (pixmode): a 16-B unit is one NHWC4 pixel (fp32) or two pixels (bf16; units 4-7 are the next image row)
+                const int iy = oy * p.stride + (pix && BF ? unit >> 2 : 0);
+                const int ix = ox * p.stride + (pix ? (BF ? (unit & 3) * 2 : unit) : 0);
+                a_vo[i] = live ? (unsigned)(((s * p.H + iy) * p.W + ix) * p.Cs * ESZ + (pix ? 0 : unit * 16)) : 0u;
+                // bit t2: tap t2 reads inside the image.  1x1 and 3x3 (pad 1) grids in closed form; any other tap
+                // table (7x7 rows of conv1, the transposed conv's phases) by walking it
+                const unsigned vx = (ix >= 1 ? 1u : 0u) | 2u | (ix + 1 < p.W ? 4u : 0u);
+                const unsigned m3 = (iy >= 1 ? vx : 0u) | (vx << 3) | (iy + 1 < p.H ? vx << 6 : 0u);
+                unsigned mk = a.tapgrid == 1 ? 1u : m3;
+                if (a.tapgrid == 0) {  // (wave-uniform)
+                    mk = 0;
+                    for (int t2 = 0; t2 < h.ntaps; t2++) {
+                        const int y = iy + tap_dy(tb + t2), x = ix + tap_dx(tb + t2);
+                        mk |= ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W ? 1u : 0u) << t2;
                     }
                 }
+                a_mask[i] = live ? mk : 0u;
             }
+            tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = __builtin_amdgcn_readfirstlane(it.c0 - tap * h.cpt);
+            rem = __builtin_amdgcn_readfirstlane(it.cnt);
+            set_tap(tap);
+        };
+        auto item_B = [&](const Item& it) __attribute__((always_inline)) {
             if constexpr (X3) {
                 // A step's weights are KG x 3 planes x BN rows x 64 B = 12 blocks of 16 rows: wave w lands blocks 3 w .. 3 w + 2.  Block ->
                 // (K group, plane, 16-row group); LDS slot (row, 16-byte unit lane & 3) takes source unit (lane & 3) ^ ((row >> 2) & 3) --
@@ -775,25 +796,31 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                 for (int i = 0; i < BRB; i++) b_vo[i] = (unsigned)(((it.n0 + srow + 32 * i) * p.K + unit * EPU) * ESZ);
                 soB = (unsigned)__builtin_amdgcn_readfirstlane((int)((it.phase * p.w_phase_stride + (long long)it.c0 * (EPR * KG)) * ESZ));
             }
-            tap = __builtin_amdgcn_readfirstlane(fdiv(it.c0, p.mg_cpt, h.cpt)), cc = __builtin_amdgcn_readfirstlane(it.c0 - tap * h.cpt);
-            rem = __builtin_amdgcn_readfirstlane(it.cnt);
-            set_tap(tap);
         };
-        auto issue = [&](int stage) __attribute__((always_inline)) {
+        auto begin_item = [&](int j) __attribute__((always_inline)) {
+            const Item it = decode(j);
+            item_B(it);
+            item_A(it);
+        };
+        constexpr unsigned STEP_B = X3 ? 0u : 128u * KG;  // (X3: 192 * KG * Npad, a run-time step)
+        // the LDS-DMA instructions of one chunk: activations (DO_A) and / or weights (DO_B; offB: the weights of a chunk further on)
+        auto loads = [&](int stage, auto DO_A, auto DO_B, unsigned offB) __attribute__((always_inline)) {
             // stage base and scalar offsets are wave-uniform: say so at the use (if register pressure ever pushes this state
             // machine into VGPRs -- the PROF = 2 build did -- each DMA would otherwise be wrapped in a readfirstlane waterfall loop)
             float* sb = smem + __builtin_amdgcn_readfirstlane(stage) * STAGE + wave * (8 * 32);  // the hardware adds lane * 16 B
-            const unsigned uA = (unsigned)__builtin_amdgcn_readfirstlane((int)soA), uB = (unsigned)__builtin_amdgcn_readfirstlane((int)soB);
+            const unsigned uA = (unsigned)__builtin_amdgcn_readfirstlane((int)soA), uB = (unsigned)__builtin_amdgcn_readfirstlane((int)(soB + offB));
 #pragma unroll
             for (int k = 0; k < KG; k++) {  // K group k: the k-th 128-byte run of the step, landed in its own image
+                if constexpr (decltype(DO_A)::value) {
 #pragma unroll
-                for (int i = 0; i < (SPAN ? 1 : ARB); i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
-                if constexpr (!X3) {
+                    for (int i = 0; i < (SPAN ? 1 : ARB); i++) bload_lds(srdA, sb + k * SUB + i * (32 * 32), a_cur[i], uA + k * 128);
+                }
+                if constexpr (!X3 && decltype(DO_B)::value) {
 #pragma unroll
                     for (int i = 0; i < BRB; i++) bload_lds(srdB, sb + k * SUB + BM * 32 + i * (32 * 32), b_vo[i], uB + k * 128);
                 }
             }
-            if constexpr (X3) {
+            if constexpr (X3 && decltype(DO_B)::value) {
                 constexpr int PER_KG = 3 * BN / 16, RG = BN / 16;
                 float* s0 = smem + __builtin_amdgcn_readfirstlane(stage) * STAGE;
 #pragma unroll
@@ -806,6 +833,8 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                     bload_lds(srdB, s0 + kgi * SUB + BM * 32 + pl * (BN * 16) + rg * 256, b_vo3[j], uB);
                 }
             }
+        };
+        auto advance = [&]() __attribute__((always_inline)) {
             rem = __builtin_amdgcn_readfirstlane(rem - 1);
             if (rem == 0) {
                 if constexpr (!SINGLE) {  // (a one-item launch has nothing behind its last chunk)
@@ -816,6 +845,10 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                 soA += 128 * KG, soB += X3 ? 192 * KG * a.Npad : 128 * KG;
                 if (++cc == h.cpt) cc = 0, set_tap(++tap);
             }
+        };
+        auto issue = [&](int stage) __attribute__((always_inline)) {
+            loads(stage, std::true_type{}, std::true_type{}, 0u);
+            advance();
         };
         auto wait_landed = [&](int young) __attribute__((always_inline)) {  // all but the `young` youngest chunks (NLD instructions each) have landed
             switch (young) {
@@ -844,8 +877,6 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         }
         const bool pst = P2 && threadIdx.x == 256 && blockIdx.x == 0;
         if (pst) prof[22] = __builtin_amdgcn_s_memrealtime();  // producer wave 0: arguments pinned, about to decode the first item
-        begin_item(0);
-        if (pst) prof[23] = __builtin_amdgcn_s_memrealtime();  // first item decoded
         // The consumers can start as soon as chunk 0 has landed, so only chunks 0 and 1 are requested before the first
         // barrier; the rest of the ring is filled behind it, two chunks per iteration until NS-1 are in flight.  (Filling
         // the whole ring first kept the matrix pipes waiting for 0.6-1.5 us of producer bookkeeping per launch.)
@@ -854,10 +885,35 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
             issue(istage);
             istage = istage + 1 == NS ? 0 : istage + 1, nis++;
         };
-        put();
-        if (G > 1) put();
-        if (pst) prof[14] = __builtin_amdgcn_s_memrealtime();  // chunks 0 and 1 requested
-        wait_landed(nis - 1);
+        constexpr bool BFIRST = SINGLE && !X3;
+        if constexpr (BFIRST) {
+            // one-item launch: the WEIGHTS of chunks 0 and 1 are requested as soon as the item is known -- their addresses need no pixel
+            // decode -- so their way from the Infinity Cache overlaps the ~100 instructions of the activation side's set-up.  Request
+            // order B0 B1 A0 A1: chunk 0 is complete once all but A1's instructions have landed.
+            const Item it = decode(0);
+            item_B(it);
+            loads(0, std::false_type{}, std::true_type{}, 0u);
+            if (G > 1) loads(1, std::false_type{}, std::true_type{}, STEP_B);
+            item_A(it);
+            if (pst) prof[23] = __builtin_amdgcn_s_memrealtime();  // first item decoded
+            loads(0, std::true_type{}, std::false_type{}, 0u);
+            advance();
+            if (G > 1) {
+                loads(1, std::true_type{}, std::false_type{}, 0u);
+                advance();
+            }
+            nis = G > 1 ? 2 : 1, istage = nis;  // (NS >= 3)
+            if (pst) prof[14] = __builtin_amdgcn_s_memrealtime();  // chunks 0 and 1 requested
+            if (G > 1) wait_vm<KG * (SPAN ? 1 : ARB)>();
+            else wait_vm<0>();
+        } else {
+            begin_item(0);
+            if (pst) prof[23] = __builtin_amdgcn_s_memrealtime();  // first item decoded
+            put();
+            if (G > 1) put();
+            if (pst) prof[14] = __builtin_amdgcn_s_memrealtime();  // chunks 0 and 1 requested
+            wait_landed(nis - 1);
+        }
         __builtin_amdgcn_s_barrier();  // chunk 0 visible
         if (G > 2) put();
         const bool pacct = P2 && threadIdx.x == 256 && blockIdx.x == 0;  // tuning aid: where producer wave 0 spends its time
@@ -1759,6 +1815,8 @@ static hipError_t setup_stream_rest()
             if (fa.numRegs > 256 || fa.localSizeBytes != 0) return hipErrorLaunchOutOfResources;
         }
     }
+    const void* span_twin = nullptr;  // conv1's span form with start / end stamps (VNECT_NO_STEM=1 under the profiling twin): may spill 8 bytes
+    if constexpr (BM == 64 && BN == 64 && KG == 1) span_twin = (const void*)conv_stream_kernel<64, 64, 1, NS, false, 1, 0, true>;
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds<BM, BN, KG, NS>());
         if (e != hipSuccess) return e;
@@ -1767,7 +1825,7 @@ static hipError_t setup_stream_rest()
         // the launch plan assumes two workgroups per CU (one for the K-group shapes): refuse a build that needs more registers
         // or scratch (the per-phase tuning twins, PROF = 2, may spill a few bytes)
         const bool twin = f == (const void*)conv_stream_kernel<BM, BN, KG, NS, false, 2> || f == (const void*)conv_stream_kernel<BM, BN, KG, NS, true, 2> ||
-                          f == twins_one[0] || f == twins_one[1];
+                          f == twins_one[0] || f == twins_one[1] || f == span_twin;
         if (fa.numRegs > (KG == 1 && BN <= 64 ? 128 : 256) || (fa.localSizeBytes != 0 && !twin)) return hipErrorLaunchOutOfResources;
     }
     return hipSuccess;
