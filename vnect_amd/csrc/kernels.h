@@ -8,7 +8,7 @@
 namespace vnect {
 
 constexpr int MAX_TAPS = 16;
-constexpr int ARG_SLABS = 8;    // arg-max workgroups per joint (6 row segments each)
+constexpr int ARG_SLABS_MAX = 32;  // upper bound of the arg-max workgroups per joint (post.hip: ARG_SLABS): what the partials' buffer is sized for
 constexpr int PROF_WGS = 512;   // largest conv grid (two workgroups per CU)
 constexpr int PROF_SLOTS = 24;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
 

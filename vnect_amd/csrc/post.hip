@@ -97,7 +97,10 @@ __device__ __forceinline__ double merged_cell(const float* __restrict__ maps, co
             const float* M = maps + (long long)i * HM * HM * MAPC + ch;
             const float* R0 = M + (long long)Y[i].s0 * HM * MAPC;
             const float* R1 = M + (long long)Y[i].s1 * HM * MAPC;
-            p00[i] = R0[X[i].s0 * MAPC], p01[i] = R0[X[i].s1 * MAPC], p10[i] = R1[X[i].s0 * MAPC], p11[i] = R1[X[i].s1 * MAPC];
+            p00[i] = R0[X[i].s0 * MAPC];
+            p01[i] = p10[i] = p11[i] = 0.f;
+            if (!geo.copy[i])  // (uniform: a scale that is a plain copy uses tap (s0, s0) alone -- a quarter of its requests)
+                p01[i] = R0[X[i].s1 * MAPC], p10[i] = R1[X[i].s0 * MAPC], p11[i] = R1[X[i].s1 * MAPC];
         }
     }
     double acc = 0.0;
@@ -122,8 +125,19 @@ __device__ __forceinline__ double merged_cell(const float* __restrict__ maps, co
 // and keeps (max value, lowest flat index) = np.argmax's first maximum.
 __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-constexpr int ARG_THREADS = 384;  // one thread per column (368 used)
-constexpr int ARG_SEGS = 6;       // 8-row segments per workgroup: 8 slabs x 6 >= 47 segments, 168 workgroups keep the f64 work off one CU
+#ifndef ARG_ROWSPLIT
+#define ARG_ROWSPLIT 1  // thread groups that share a workgroup's row segments (A/B builds: 2 = 768 threads, each column's segments in two halves)
+#endif
+constexpr int ARG_COLS = 384;                       // one thread per column (368 used) ...
+constexpr int ARG_THREADS = ARG_COLS * ARG_ROWSPLIT;  // ... times the row split
+// Workgroups per joint and 8-row segments per workgroup (47 segments in all): 8 x 6 = 168 workgroups keep the f64 work off one CU.  Round 5,
+// in-frame averages of post_kernel under rocprofv3 (tools/kernel_avg.sh, -DARG_SLABS=n builds, one call): 4 slabs 14.5 us, 6 12.8, 8 12.4-12.5,
+// 16 13.1, 24 15.3 -- every workgroup more is one more arrival at the ticket, every workgroup fewer doubles the f64 blends per column.
+#ifndef ARG_SLABS
+#define ARG_SLABS 8
+#endif
+static_assert(ARG_SLABS <= ARG_SLABS_MAX, "the partials' buffer is sized for ARG_SLABS_MAX slabs per joint");
+constexpr int ARG_SEGS = (47 + ARG_SLABS - 1) / ARG_SLABS;
 
 // (max value, lowest flat index) over the 64 lanes of a wave by butterfly exchanges (DPP / ds_bpermute under __shfl_xor): every lane
 // ends with the wave's winner.  `better` is a total order on (v, i) pairs with distinct i, so the result does not depend on the
@@ -138,6 +152,10 @@ __device__ __forceinline__ void wave_argmax(double& v, int& i)
     }
 }
 
+#ifndef POST_DBG
+#define POST_DBG 0  // tuning builds only (tools/post_breakdown.sh; wrong results): 1 = no joints stage, 2 = also no merge (no map loads),
+                    // 3 = also no x8 upsample / arg-max arithmetic, 4 = an empty kernel (the launch's floor)
+#endif
 template <int SMAX>
 __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, const MergeGeo& geo, ArgPartial* __restrict__ part)
 {
@@ -146,7 +164,7 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
     __shared__ int wi[ARG_THREADS / 64];
     const int j = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
     // this thread's column of the x8 upsample (utils.py:169-171: cv2.resize(hm f64, fx=fy=8); hostplan.h: build_up_tab)
-    const int x = tid, xc = x < BOX ? x : BOX - 1;
+    const int x = tid % ARG_COLS, part_of = tid / ARG_COLS, xc = x < BOX ? x : BOX - 1;
     const AxE ux = axis_x_at(xc, HM, 1.0 / 8.0);
     const int sx = ux.s0, edge = ux.edge;
     const double a0 = (double)(1.f - ux.f), a1 = (double)ux.f;
@@ -157,7 +175,7 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
         const int cells = (r_hi - r_lo + 1) * HM;
         for (int p = tid; p < cells; p += ARG_THREADS) {
             const int r = r_lo + p / HM, c = p % HM;
-            map[r * HM + c] = merged_cell<SMAX>(maps, geo, j, r, c);
+            map[r * HM + c] = POST_DBG == 2 ? (double)(r * 3 + c) : merged_cell<SMAX>(maps, geo, j, r, c);
         }
     }
     __syncthreads();
@@ -166,7 +184,7 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
     // with the weights of row 4 + p.  Segment 0 has phases 4..7 (rows 0..3), segment 46 phases 0..3 (rows 364..367).
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
-    if (x < BOX) {
+    if (x < BOX && POST_DBG != 3) {
         double w0[8], w1[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) {
@@ -177,7 +195,9 @@ __device__ __forceinline__ void argmax_body(const float* __restrict__ maps, cons
             const double* R = map + sy * HM;
             return edge ? R[sx] : R[sx] * a0 + R[sx + 1] * a1;
         };
-        const int g0 = slab * ARG_SEGS, g1 = g0 + ARG_SEGS < 47 ? g0 + ARG_SEGS : 47;
+        const int s0 = slab * ARG_SEGS, s1 = s0 + ARG_SEGS < 47 ? s0 + ARG_SEGS : 47;  // the slab's segments, shared out over the row split
+        const int per = (s1 - s0 + ARG_ROWSPLIT - 1) / ARG_ROWSPLIT;
+        const int g0 = s0 + part_of * per, g1 = g0 + per < s1 ? g0 + per : s1;
         double h1 = hrow(g0 > 0 ? g0 - 1 : 0);
         for (int g = g0; g < g1; g++) {
             const double h0 = h1;
@@ -233,34 +253,52 @@ __device__ __forceinline__ double lowpass(int& init, double& y, double& s, doubl
     s = r;
     return r;
 }
-__device__ __forceinline__ void oef_time(Filt& f, double t)
+// A filter step in two halves (round 5): what does not depend on the value being filtered -- the frequency update of OneEuroFilter.py:65-66,
+// te = 1 / freq and the derivative filter's alpha -- and the rest.  post_kernel computes the first half while it waits for memory, BEFORE it
+// knows the arg-max; the arithmetic (every operation and its order) is that of the one-piece form, which is now written in terms of the halves.
+struct OefPrep {
+    double freq, te, a_d;
+};
+__device__ __forceinline__ OefPrep oef_prep(const Filt& f, double t)
 {
+    OefPrep p;
     // `if self.__lasttime and timestamp:` -- None and 0.0 are falsy.  t == lasttime is rejected by the host.
-    if (f.has_last && f.lasttime != 0.0 && t != 0.0) f.freq = 1.0 / (t - f.lasttime);
-    f.lasttime = t;
-    f.has_last = 1;
+    p.freq = (f.has_last && f.lasttime != 0.0 && t != 0.0) ? 1.0 / (t - f.lasttime) : f.freq;
+    p.te = 1.0 / p.freq;
+    p.a_d = 1.0 / (1.0 + (1.0 / (2 * 3.141592653589793 * f.dcutoff)) / p.te);  // oef_alpha(freq, dcutoff)
+    return p;
 }
-__device__ double oef_f64(Filt& f, double x, double t)
+__device__ __forceinline__ double oef_alpha_te(double te, double cutoff)  // oef_alpha with 1 / freq at hand
 {
-    oef_time(f, t);
-    const double dx = f.x_init ? (x - f.x_y) * f.freq : 0.0;
-    const double edx = lowpass(f.dx_init, f.dx_y, f.dx_s, dx, oef_alpha(f.freq, f.dcutoff));
-    const double cutoff = f.mincutoff + f.beta * fabs(edx);
-    return lowpass(f.x_init, f.x_y, f.x_s, x, oef_alpha(f.freq, cutoff));
+    const double tau = 1.0 / (2 * 3.141592653589793 * cutoff);
+    return 1.0 / (1.0 + tau / te);
 }
+__device__ __forceinline__ void oef_commit_time(Filt& f, const OefPrep& p, double t)
+{
+    f.freq = p.freq, f.lasttime = t, f.has_last = 1;
+}
+__device__ __forceinline__ double oef_f64_fin(Filt& f, const OefPrep& p, double x, double t)
+{
+    oef_commit_time(f, p, t);
+    const double dx = f.x_init ? (x - f.x_y) * f.freq : 0.0;
+    const double edx = lowpass(f.dx_init, f.dx_y, f.dx_s, dx, p.a_d);
+    const double cutoff = f.mincutoff + f.beta * fabs(edx);
+    return lowpass(f.x_init, f.x_y, f.x_s, x, oef_alpha_te(p.te, cutoff));
+}
+__device__ double oef_f64(Filt& f, double x, double t) { return oef_f64_fin(f, oef_prep(f, t), x, t); }
 // The 3-D filters are fed np.float32 scalars (estimator.py:91-93), so numpy's scalar promotion decides
 // the arithmetic: numpy 1.x (nep50 = 0): float32 (op) Python float -> float64, float32 - float32 -> float32;
 // numpy >= 2 (nep50 = 1): Python floats are weak, everything stays float32.
-__device__ float oef_f32(Filt& f, float x, double t, int nep50)
+__device__ __forceinline__ float oef_f32_fin(Filt& f, const OefPrep& p, float x, double t, int nep50)
 {
-    oef_time(f, t);
-    const double a_d = oef_alpha(f.freq, f.dcutoff);
+    oef_commit_time(f, p, t);
+    const double a_d = p.a_d;
     if (!nep50) {
         const float diff = x - (float)f.x_y;
         const double dx = f.x_init ? (double)diff * f.freq : 0.0;
         const double edx = lowpass(f.dx_init, f.dx_y, f.dx_s, dx, a_d);
         const double cutoff = f.mincutoff + f.beta * fabs(edx);
-        return (float)lowpass(f.x_init, f.x_y, f.x_s, (double)x, oef_alpha(f.freq, cutoff));
+        return (float)lowpass(f.x_init, f.x_y, f.x_s, (double)x, oef_alpha_te(p.te, cutoff));
     }
     float edx;
     if (!f.x_init) {
@@ -273,11 +311,12 @@ __device__ float oef_f32(Filt& f, float x, double t, int nep50)
         edx = s;
     }
     const double cutoff = f.mincutoff + f.beta * fabs((double)edx);
-    const double a_x = oef_alpha(f.freq, cutoff);
+    const double a_x = oef_alpha_te(p.te, cutoff);
     const float r = f.x_init ? (float)a_x * x + (float)(1.0 - a_x) * (float)f.x_s : x;
     f.x_init = 1, f.x_y = x, f.x_s = r;
     return r;
 }
+__device__ float oef_f32(Filt& f, float x, double t, int nep50) { return oef_f32_fin(f, oef_prep(f, t), x, t, nep50); }
 
 // utils.hm_pt_interp_bilinear (utils.py:58-79), scale 8, on merged map q (channel ch) evaluated cell by cell
 template <int SMAX>
@@ -384,16 +423,118 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
 // states and un-mapping constants -> registers) before anything else, so the last arriver starts no memory round trip for them;
 // the resize geometry travels in the kernel arguments (MergeGeo) and every table entry is computed where it is used; on a pyramid-sharded handle a frame whose exchange failed (dyn.xfail) skips the
 // joints stage -- the filter banks do not advance on stale maps -- and reports status 1.
+// The joints stage of post_kernel, spread over the last arriver's six waves (round 5; joints_body above is the 128-thread form of the
+// stand-alone joints_kernel and gives the same bits).  The one-wave form cost ~7 of the launch's 15 us: ~2 500 instructions on ONE
+// wave's dependent stream -- 4 merged cells x 3 scales of axis arithmetic per read-off, two filter steps with their f64 divisions --
+// behind three memory round trips.  Here: wave 0 = the 42 2-D filters, wave 1 = the 63 3-D filters, waves 2..5 = one thread per
+// (read-off, corner) = 252 merged cells, each evaluated once; the value-independent half of every filter step (oef_prep) is computed
+// by every workgroup while it waits for its partial's store, before the ticket says who is last.
+struct WideRole {
+    int j2, k2, j3, k3;
+};
+__device__ __forceinline__ WideRole wide_role()
+{
+    const int t = threadIdx.x, u = t - 64;
+    WideRole r;
+    r.j2 = t < NJ * 2 ? t >> 1 : 0, r.k2 = t & 1;
+    r.j3 = (u >= 0 && u < NJ * 3) ? u / 3 : 0, r.k3 = (u >= 0 && u < NJ * 3) ? u - 3 * r.j3 : 0;
+    return r;
+}
+template <int SMAX>
+__device__ __forceinline__ void joints_stage_wide(const ArgPartial* part, const float* __restrict__ maps, const MergeGeo& geo, FilterBank* fb,
+                                                  Filt& f2, Filt& f3, const OefPrep& pr2, const OefPrep& pr3, double scaler, double off,
+                                                  const FrameDyn& dyn, int nep50, JointsOut* __restrict__ out)
+{
+    __shared__ double c2[NJ * 2];
+    __shared__ double mc[NJ * 3 * 4];
+    __shared__ float p3[NJ * 3];
+    const int t = threadIdx.x, u = t - 64, v = t - 128;
+    const WideRole ro = wide_role();
+    if (t < NJ * 2) {  // wave 0: arg-max of the 8 slab partials, 2-D filter step
+        double pv[ARG_SLABS];
+        int pi[ARG_SLABS];
+#pragma unroll
+        for (int sl = 0; sl < ARG_SLABS; sl++) {  // `sc1` loads: the partials were written by other workgroups of this launch
+            pv[sl] = __hip_atomic_load(&part[ro.j2 * ARG_SLABS + sl].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pi[sl] = __hip_atomic_load(&part[ro.j2 * ARG_SLABS + sl].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double bv = pv[0];
+        int bi = pi[0];
+#pragma unroll
+        for (int sl = 1; sl < ARG_SLABS; sl++)  // slabs ascend in row order
+            if (better(pv[sl], pi[sl], bv, bi)) bv = pv[sl], bi = pi[sl];
+        if (bi == 0x7fffffff) bi = 0;  // all-NaN map: np.argmax would return the first NaN; documented deviation
+        const double raw = ro.k2 == 0 ? (double)(bi / BOX) : (double)(bi % BOX);  // [row, col]
+        c2[t] = oef_f64_fin(f2, pr2, raw, dyn.t2d);
+        fb->f2[ro.j2][ro.k2] = f2;
+    }
+    __syncthreads();
+    // utils.hm_pt_interp_bilinear (utils.py:58-79) of read-off r = (joint, map) at the filtered 2-D joint: its source coordinates and corners
+    auto corners = [&](int r, double& src_x, double& src_y, int& x0, int& y0, int& x1, int& y1) {
+        const int j = r / 3;
+        src_x = (c2[j * 2 + 1] + 0.5) / 8.0 - 0.5;
+        src_y = (c2[j * 2] + 0.5) / 8.0 - 0.5;
+        x0 = (int)src_x, y0 = (int)src_y;  // int(): truncation toward zero
+        x0 = x0 < 0 ? 0 : (x0 > HM - 1 ? HM - 1 : x0);  // no-ops for finite filtered joints in [0, 367];
+        y0 = y0 < 0 ? 0 : (y0 > HM - 1 ? HM - 1 : y0);  // keep NaN inputs from indexing outside the map
+        x1 = x0 + 1 < HM - 1 ? x0 + 1 : HM - 1;
+        y1 = y0 + 1 < HM - 1 ? y0 + 1 : HM - 1;
+    };
+    if (v >= 0 && v < NJ * 3 * 4) {  // waves 2..5: one merged cell each
+        const int r = v >> 2, cell = v & 3, j = r / 3, k = r - 3 * j;
+        double sx, sy;
+        int x0, y0, x1, y1;
+        corners(r, sx, sy, x0, y0, x1, y1);
+        mc[v] = merged_cell<SMAX>(maps, geo, (k + 1) * NJ + j, (cell & 2) ? y1 : y0, (cell & 1) ? x1 : x0);
+    }
+    __syncthreads();
+    if (u >= 0 && u < NJ * 3) {  // wave 1: the bilinear blend of pt_interp, x 100 (estimator.py:135), in float32
+        double src_x, src_y;
+        int x0, y0, x1, y1;
+        corners(u, src_x, src_y, x0, y0, x1, y1);
+        const double m00 = mc[u * 4], m01 = mc[u * 4 + 1], m10 = mc[u * 4 + 2], m11 = mc[u * 4 + 3];
+        const double v0 = (x1 - src_x) * m00 + (src_x - x0) * m01;
+        const double v1 = (x1 - src_x) * m10 + (src_x - x0) * m11;
+        p3[u] = (float)(((y1 - src_y) * v0 + (src_y - y0) * v1) * 100);
+    }
+    __syncthreads();
+    if (u >= 0 && u < NJ * 3) {
+        const float d = p3[u] - p3[14 * 3 + ro.k3];  // joints_3d -= joints_3d[14, :] in float32
+        out->j3d[u] = oef_f32_fin(f3, pr3, d, dyn.t3d, nep50);
+        fb->f3[ro.j3][ro.k3] = f3;
+    }
+    if (t < NJ * 2) out->j2d[t] = (c2[t] - off) / scaler;
+    if (t == 0) out->status = 0;
+}
+
+// Both in ONE launch (round 2): the 168 arg-max workgroups publish their partials write-through and take an agent-scope ticket; the
+// workgroup whose ticket comes last -- every partial is then in memory -- runs the joints stage (filters, read-off, un-mapping).
+// Nobody waits: the other workgroups are gone by then.  The hand-off is, cell for cell, the first row of
+// MI355X_MICROARCH.md's table of hand-offs measured valid with `sc1` loads in place of an acquire: ONE lane per storing workgroup stores
+// its bytes `sc1` (8- and 4-byte), waits vmcnt(0), adds to ONE unsharded agent-scope counter; the workgroup whose add came last loads
+// (`sc1`, 8- and 4-byte) only after its add has returned, its other waves behind a workgroup barrier.  An explicit release / acquire
+// pair instead (buffer_wbl2 sc1 / buffer_inv sc1) is priced at ~1.7 us EACH in the same guide, on the critical path of a kernel
+// that is nothing but a chain of round trips -- so the relaxed form stays, and this comment is what keeps it honest: any change
+// to the store / wait / add / load sequence must be checked against that table again.
+// Round 3: every workgroup requests what the joints stage needs that does not depend on the arg-max (filter states and un-mapping
+// constants -> registers) before anything else, so the last arriver starts no memory round trip for them;
+// the resize geometry travels in the kernel arguments (MergeGeo) and every table entry is computed where it is used; on a pyramid-sharded handle a frame whose exchange failed (dyn.xfail) skips the
+// joints stage -- the filter banks do not advance on stale maps -- and reports status 1.
+// Round 5: the joints stage runs on all six waves of the last arriver (joints_stage_wide), and the value-independent half of the filter
+// steps is computed here, in every workgroup, between the partial's store and the wait for it.
 template <int SMAX>
 __global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restrict__ maps, const MergeGeo geo, ArgPartial* part, unsigned* ticket,
                                                            FilterBank* fb, const FrameParams* __restrict__ fp, const FrameDyn dyn,
                                                            int nep50, JointsOut* __restrict__ out)
 {
     __shared__ int last;
-    Filt f2, f3;
-    double scaler, off;
-    load_filters(fb, fp, f2, f3, scaler, off);
+    if (POST_DBG == 4) return;
+    // this thread's filter states and un-mapping constants in the roles of joints_stage_wide (other threads hold copies of filter 0's: never written back)
+    const WideRole ro = wide_role();
+    Filt f2 = fb->f2[ro.j2][ro.k2], f3 = fb->f3[ro.j3][ro.k3];
+    const double scaler = fp->scaler, off = ro.k2 == 0 ? (double)fp->offy : (double)fp->offx;
     argmax_body<SMAX>(maps, geo, part);
+    const OefPrep pr2 = oef_prep(f2, dyn.t2d), pr3 = oef_prep(f3, dyn.t3d);  // (thread 0: behind its partial's stores, in front of the wait for them)
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's `sc1` stores of the partial have left (write-through)
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -401,12 +542,12 @@ __global__ __launch_bounds__(ARG_THREADS) void post_kernel(const float* __restri
         if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next frame
     }
     __syncthreads();  // the other waves of the last arriver load the partials (sc1) only behind this barrier
-    if (!last) return;
+    if (!last || (POST_DBG >= 1 && POST_DBG <= 3)) return;
     if (dyn.xfail && __hip_atomic_load(dyn.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == dyn.xseq) {
         if (threadIdx.x == 0) out->status = 1;  // the exchange of THIS frame timed out: stale maps, leave the filters alone
         return;
     }
-    joints_body<SMAX>(part, maps, geo, fb, f2, f3, scaler, off, dyn, nep50, out);
+    joints_stage_wide<SMAX>(part, maps, geo, fb, f2, f3, pr2, pr3, scaler, off, dyn, nep50, out);
 }
 hipError_t launch_post(const float* maps, MergeGeo geo, ArgPartial* part, unsigned* ticket, FilterBank* fb, const FrameParams* fp,
                        FrameDyn dyn, int nep50, JointsOut* out, hipStream_t st)

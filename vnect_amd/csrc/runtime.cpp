@@ -1266,7 +1266,7 @@ int build_twin(vnect_handle* h)
     t->slots = h->slots;
     int rc;
     if ((rc = dev_alloc(t, &t->d_fp, 1))) return fail(h, rc, t->err);
-    if ((rc = dev_alloc(t, &t->d_part, (size_t)NJ * ARG_SLABS))) return fail(h, rc, t->err);
+    if ((rc = dev_alloc(t, &t->d_part, (size_t)NJ * ARG_SLABS_MAX))) return fail(h, rc, t->err);
     if ((rc = dev_alloc(t, &t->d_ticket, 4))) return fail(h, rc, t->err);
     HIPCK(h, hipMemset(t->d_ticket, 0, 4 * sizeof(unsigned)));
     t->post_merged = h->post_merged;
@@ -1656,7 +1656,7 @@ int vnect_create(const vnect_config* cfg, vnect_handle** out)
         if (!pre && (rc = dev_alloc(h, &h->frames, (size_t)h->cfg.num_frame_slots * h->cfg.max_frame_bytes + 16))) return rc;  // + slack: a dword read may run 3 bytes past a frame's last pixel
         if ((rc = dev_alloc(h, &h->d_fp, 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_stabs, 1))) return rc;
-        if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS))) return rc;
+        if ((rc = dev_alloc(h, &h->d_part, (size_t)NJ * ARG_SLABS_MAX))) return rc;
         if ((rc = dev_alloc(h, &h->d_ticket, 4))) return rc;
         HIPCK(h, hipMemset(h->d_ticket, 0, 4 * sizeof(unsigned)));
         h->post_merged = getenv("VNECT_NO_POST_MERGE") == nullptr;
