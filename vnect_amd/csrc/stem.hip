@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int STEM_CW = 2 * STEM_TW + 1;             // conv columns per tile (47)
 constexpr int STEM_LW = 48;                          // row stride of the tile's conv pixels in M (47 + one dummy): a lane's groups of four
@@ -64,7 +65,9 @@ template <bool BF, bool FRAME = false>
 constexpr size_t stem_lds()
 {
     // patch, pooled tile, (FRAME) scratch, and 512 bytes for the PAIR form's table of output-pixel offsets
-    return (size_t)STEM_PH * STEM_PW * 4 * (BF ? 2 : 4) + (size_t)STEM_MAXH * STEM_TW * 64 * 4 + (FRAME ? STEM_SCR_BYTES : 0) + 512;
+    // (bf16: at least the eight waves' output tiles of the PAIR form's write-out, 8 x 32 rows x 336 B)
+    const size_t base = (size_t)STEM_PH * STEM_PW * 4 * (BF ? 2 : 4) + (size_t)STEM_MAXH * STEM_TW * 64 * 4 + (FRAME ? STEM_SCR_BYTES : 0);
+    return (BF && base < (size_t)8 * 32 * 336 ? (size_t)8 * 32 * 336 : base) + 512;
 }
 
 // FRAME: the patch is computed from the uint8 frame instead of being copied from the batch tensor (the host takes this form only for
@@ -160,44 +163,56 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
         const int off = scaled ? a.tabs->pad[s] : 0;  // origin and size of the scaled image on the canvas
         const int dh = scaled ? t.dh : BOX, dw = scaled ? t.dw : BOX;
         const int offy = a.fp->offy, offx = a.fp->offx, FH = a.fp->sq.dh, FW = a.fp->sq.dw;  // the frame inside the square
-        // -- A: tables -> LDS
-        if (tid < 256) lut[tid] = a.tabs->lut[tid];
-        if (tid < prow) {
-            const int y = iy0 + tid, dy = y - off;
-            StemRow r = {0, 0, 0, 0, 0, {0, 0, 0}};
-            if ((unsigned)y < (unsigned)BOX) {
-                if ((unsigned)dy >= (unsigned)dh) r.kind = 1;
-                else if (!resize) r.kind = 2, r.q0 = r.q1 = (short)dy;
-                else r.kind = 3, r.q0 = t.sy0[dy], r.q1 = t.sy1[dy], r.b0 = t.b0[dy], r.b1 = t.b1[dy];
-            }
-            rows[tid] = r;
-        }
-        if (tid >= 128 && tid < 128 + STEM_PW) {
-            const int x = ix0 + tid - 128, dx = x - off;
-            StemCol q = {0, 0, 0, 0};
-            if ((unsigned)x < (unsigned)BOX) {
-                if ((unsigned)dx >= (unsigned)dw) q.kind = 1;
-                else if (!resize) q.kind = 2, q.q = (short)dx;
-                else q.kind = dx < t.xmax ? 3 : 4, q.q = t.sx[dx], q.a0 = t.a0[dx], q.a1 = t.a1[dx];
-            }
-            cols[tid - 128] = q;
-        }
-        __syncthreads();
-        // -- B: the rectangle of the square the patch reads, [qy0, qy1] x [qx0, qx1] (from the first / last patch row and column that lie
-        //    inside the scaled image), as frame bytes.  LDS row r holds square row qy0 + r; pixel qx sits at byte 3 (qx - qx0) +
-        //    rowmis[r], the offset chosen so that LDS dwords and global dwords are aligned to each other; bytes outside the frame stay 0.
+        // -- A + B in ONE memory round trip and one barrier (round 5; they used to be two of each: the rectangle was computed from the
+        //    row / column descriptors in LDS, i.e. behind the barrier that published them):
+        //    (A) tables -> LDS: the `/255 - 0.4` table, one descriptor per patch row / column;
+        //    (B) the rectangle of the square the patch reads, [qy0, qy1] x [qx0, qx1] (from the first / last patch row and column that lie
+        //    inside the scaled image), as frame bytes.  Its four corners are four UNIFORM table entries, fetched here directly (the same
+        //    entries the descriptors hold: plan::stem_frame_fits does this arithmetic on the host).  LDS row r holds square row qy0 + r;
+        //    pixel qx sits at byte 3 (qx - qx0) + rowmis[r], the offset chosen so that LDS dwords and global dwords are aligned to each
+        //    other; bytes outside the frame stay 0.
         const int ylo = iy0 > off ? iy0 : off, yhi = (iy0 + prow - 1 < off + dh - 1 ? iy0 + prow - 1 : off + dh - 1);
         const int xlo = ix0 > off ? ix0 : off, xhi = (ix0 + STEM_PW - 1 < off + dw - 1 ? ix0 + STEM_PW - 1 : off + dw - 1);
         int qy0 = 0, qx0 = 0, RH = 0, RW = 0;
-        if (ylo <= yhi && xlo <= xhi) {
-            qy0 = rows[ylo - iy0].q0, qx0 = cols[xlo - ix0].q;
-            const int qy1 = rows[yhi - iy0].q1;
-            int qx1 = cols[xhi - ix0].q + (resize ? 1 : 0);
+        if (ylo <= yhi && xlo <= xhi) {  // (uniform)
+            qy0 = resize ? t.sy0[ylo - off] : ylo - off, qx0 = resize ? t.sx[xlo - off] : xlo - off;
+            const int qy1 = resize ? t.sy1[yhi - off] : yhi - off;
+            int qx1 = resize ? t.sx[xhi - off] + 1 : xhi - off;
             if (qx1 > BOX - 1) qx1 = BOX - 1;
             RH = qy1 - qy0 + 1, RW = qx1 - qx0 + 1;  // <= STEM_REG_ROWS, 3 RW + 8 <= STEM_REG_PITCH: plan::stem_frame_fits
         }
+        qy0 = __builtin_amdgcn_readfirstlane(qy0), qx0 = __builtin_amdgcn_readfirstlane(qx0);
+        RH = __builtin_amdgcn_readfirstlane(RH), RW = __builtin_amdgcn_readfirstlane(RW);
+        const float lutv = tid < 256 ? a.tabs->lut[tid] : 0.f;
+        StemRow rdesc = {0, 0, 0, 0, 0, {0, 0, 0}};
+        if (tid < prow) {
+            const int y = iy0 + tid, dy = y - off;
+            if ((unsigned)y < (unsigned)BOX) {
+                if ((unsigned)dy >= (unsigned)dh) rdesc.kind = 1;
+                else if (!resize) rdesc.kind = 2, rdesc.q0 = rdesc.q1 = (short)dy;
+                else rdesc.kind = 3, rdesc.q0 = t.sy0[dy], rdesc.q1 = t.sy1[dy], rdesc.b0 = t.b0[dy], rdesc.b1 = t.b1[dy];
+            }
+        }
+        StemCol cdesc = {0, 0, 0, 0};
+        if (tid >= 128 && tid < 128 + STEM_PW) {
+            const int x = ix0 + tid - 128, dx = x - off;
+            if ((unsigned)x < (unsigned)BOX) {
+                if ((unsigned)dx >= (unsigned)dw) cdesc.kind = 1;
+                else if (!resize) cdesc.kind = 2, cdesc.q = (short)dx;
+                else cdesc.kind = dx < t.xmax ? 3 : 4, cdesc.q = t.sx[dx], cdesc.a0 = t.a0[dx], cdesc.a1 = t.a1[dx];
+            }
+        }
         {
-            constexpr int RPW = STEM_REG_PITCH / 4, PER = STEM_REG_ROWS * RPW / STEM_THREADS;  // 20 dwords per thread at most
+            // The rectangle's dwords, row-major with RPW = the dwords a row really needs (3 RW + 6 bytes and up to 3 of alignment), dealt
+            // over the 512 threads: slot k of this thread is dword i = tid + 512 k.  Only the first `trips` slots exist (uniform), 4-5 for
+            // a tile of the full-size image, ~12 at scale 0.6 -- the worst case the scratch admits (64 rows x 160 dwords) is 20, and every
+            // slot costs ~30 instructions of address arithmetic whether or not it holds a byte (they all ran until round 5).
+            constexpr int PER = STEM_REG_ROWS * (STEM_REG_PITCH / 4) / STEM_THREADS;  // 20 slots at most
+            const int RPW = __builtin_amdgcn_readfirstlane((3 * RW + 6 + 3 + 3) >> 2);  // <= STEM_REG_PITCH / 4
+            const int total = RH * RPW, trips = __builtin_amdgcn_readfirstlane((total + STEM_THREADS - 1) / STEM_THREADS);
+            // i / RPW in float: i + 0.5 is at least 0.5 / 160 away from a multiple of RPW, the reciprocal's and the product's rounding
+            // errors are five orders below that (i < 10 240)
+            const float rpw_inv = __builtin_amdgcn_rcpf((float)RPW);
             const int fx0 = qx0 - offx;                             // frame column of square column qx0 (may be negative)
             const int fxL = fx0 > 0 ? fx0 : 0, fxR = (fx0 + RW - 1 < FW - 1 ? fx0 + RW - 1 : FW - 1);
             const int lead = fxL - fx0, cnt = fxR - fxL + 1;        // clipped-away pixels on the left; pixels inside the frame
@@ -205,24 +220,31 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
             unsigned v[PER], msk[PER];
 #pragma unroll
             for (int k = 0; k < PER; k++) {
-                const int i = tid + k * STEM_THREADS, r = i / RPW, j = i - r * RPW;
-                const int fy = qy0 + r - offy;
-                const bool rv = i < RH * RPW && (unsigned)fy < (unsigned)FH && cnt > 0;
-                const unsigned long long G = fbase + (unsigned long long)(rv ? fy : 0) * (unsigned long long)a.dyn.row_stride + 3ull * fxL;
-                const int m = (int)((G - 3ull * lead) & 3ull);
-                const int lo = 3 * lead + m, hi = lo + 3 * cnt;       // the row's valid bytes in LDS
-                int first = lo - 4 * j, last = hi - 4 * j;
-                first = first < 0 ? 0 : first, last = last > 4 ? 4 : last;
-                const bool live = rv && last > first;
-                msk[k] = live ? (0xFFFFFFFFu >> (8 * (4 - last))) & (0xFFFFFFFFu << (8 * first)) : 0u;
-                const unsigned long long addr = live ? G - (unsigned long long)lo + 4ull * j : fbase;  // aligned either way
-                v[k] = *(__attribute__((address_space(1))) const unsigned*)addr;  // global_load_dword (a generic pointer would be a FLAT load)
-                if (j == 0 && i < RH * RPW) rowmis[r] = m;
+                if (k < trips) {  // (uniform)
+                    const int i = tid + k * STEM_THREADS, r = (int)(((float)i + 0.5f) * rpw_inv), j = i - r * RPW;
+                    const int fy = qy0 + r - offy;
+                    const bool rv = i < total && (unsigned)fy < (unsigned)FH && cnt > 0;
+                    const unsigned long long G = fbase + (unsigned long long)(rv ? fy : 0) * (unsigned long long)a.dyn.row_stride + 3ull * fxL;
+                    const int m = (int)((G - 3ull * lead) & 3ull);
+                    const int lo = 3 * lead + m, hi = lo + 3 * cnt;       // the row's valid bytes in LDS
+                    int first = lo - 4 * j, last = hi - 4 * j;
+                    first = first < 0 ? 0 : first, last = last > 4 ? 4 : last;
+                    const bool live = rv && last > first;
+                    msk[k] = live ? (0xFFFFFFFFu >> (8 * (4 - last))) & (0xFFFFFFFFu << (8 * first)) : 0u;
+                    const unsigned long long addr = live ? G - (unsigned long long)lo + 4ull * j : fbase;  // aligned either way
+                    v[k] = *(__attribute__((address_space(1))) const unsigned*)addr;  // global_load_dword (a generic pointer would be a FLAT load)
+                    if (j == 0 && i < total) rowmis[r] = m;
+                }
             }
+            if (tid < 256) lut[tid] = lutv;
+            if (tid < prow) rows[tid] = rdesc;
+            if (tid >= 128 && tid < 128 + STEM_PW) cols[tid - 128] = cdesc;
 #pragma unroll
             for (int k = 0; k < PER; k++) {
-                const int i = tid + k * STEM_THREADS;
-                if (i < RH * RPW) ((unsigned*)reg)[i] = v[k] & msk[k];
+                if (k < trips) {
+                    const int i = tid + k * STEM_THREADS, r = (int)(((float)i + 0.5f) * rpw_inv), j = i - r * RPW;
+                    if (i < total) ((unsigned*)reg)[r * (STEM_REG_PITCH / 4) + j] = v[k] & msk[k];
+                }
             }
         }
         __syncthreads();
@@ -367,29 +389,37 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
         typedef __attribute__((address_space(1))) const f32x4 cgf4;
         constexpr int NQ = BF ? 4 : 8;
         const int npx = h * STEM_TW, rb = wave & 3, cb0 = 5 * (wave >> 2);
-        if (rb * 32 < npx) {  // (uniform)
-            int ia = rb * 32 + col;
-            if (ia >= npx) ia = 0;  // rows past the tile read pixel 0: finite values, results unused
-            f32x4 Af[NQ];
+        const bool active = rb * 32 < npx && !(a.dbg & 16);  // (uniform; dbg 16: no pair GEMM at all)
+        int ia = rb * 32 + col;  // (a wave without a row block reads pixel 0 like the rows past the tile: unused)
+        if (ia >= npx) ia = 0;  // rows past the tile read pixel 0: finite values, results unused
+        f32x4 Af[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                if constexpr (BF) {  // the pooled values are bf16 numbers held as fp32 (rounded before the max): the conversion is exact
-                    const f32x4 lo = *(const f32x4*)(pooled + ia * 64 + 16 * q + 8 * hh), hi = *(const f32x4*)(pooled + ia * 64 + 16 * q + 8 * hh + 4);
-                    const bf16x8 v = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
-                    Af[q] = __builtin_bit_cast(f32x4, v);
-                } else
-                    Af[q] = *(const f32x4*)(pooled + ia * 64 + 8 * q + 4 * hh);
-            }
-            // output pixel offsets of the lane's 16 C/D rows (row = (r & 3) + 8 (r >> 2) + 4 hh): four 16-byte reads of the table
-            unsigned offa[16];
+        for (int q = 0; q < NQ; q++) {
+            if constexpr (BF) {  // the pooled values are bf16 numbers held as fp32 (rounded before the max): the conversion is exact
+                const f32x4 lo = *(const f32x4*)(pooled + ia * 64 + 16 * q + 8 * hh), hi = *(const f32x4*)(pooled + ia * 64 + 16 * q + 8 * hh + 4);
+                const bf16x8 v = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+                Af[q] = __builtin_bit_cast(f32x4, v);
+            } else
+                Af[q] = *(const f32x4*)(pooled + ia * 64 + 8 * q + 4 * hh);
+        }
+        // output pixel offsets of the lane's 16 C/D rows (row = (r & 3) + 8 (r >> 2) + 4 hh): four 16-byte reads of the table
+        unsigned offa[16];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 t4 = *(const u32x4*)(pixtab + rb * 32 + 4 * hh + 8 * g4);
+        for (int g4 = 0; g4 < 4; g4++) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t4 = *(const u32x4*)(pixtab + rb * 32 + 4 * hh + 8 * g4);
 #pragma unroll
-                for (int e = 0; e < 4; e++) offa[4 * g4 + e] = t4[e];
-            }
+            for (int e = 0; e < 4; e++) offa[4 * g4 + e] = t4[e];
+        }
+        // bf16: the output leaves through LDS tiles laid over the patch / pooled / scratch areas: every wave must have read its A fragments
+        // and table entries (above) before any wave writes there
+        if constexpr (BF) __syncthreads();
+        if (active) {
             cgf4* bp = (cgf4*)a.pair_w + lane;
+            // bf16: this wave's output tile in LDS, over the patch / pooled / scratch areas -- every wave has its A fragments in registers,
+            // but waves still READING theirs must be past that point before anyone writes here: the barrier below
+            constexpr int WT_LD = 168;  // row stride in elements: 336 B, 16-byte aligned, rows 4 banks apart
+            __bf16* const wtile = (__bf16*)smem + wave * (32 * WT_LD);
             f32x4 Bc[NQ], Bn[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) Bc[q] = bp[(cb0 * NQ + q) * 64], Bn[q] = Bc[q];
@@ -419,13 +449,41 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
                 // columns 0..63 = res2a_branch2a (ReLU), 64..319 = res2a_branch1 (none): uniform per block
                 const bool first = cb < 2;
                 T* ob = first ? (T*)a.pair_out_a + n2 : (T*)a.pair_out_b + (n2 - 64);
+                if constexpr (BF) {
+                    // bf16: the block goes to this wave's LDS tile [32 rows][160 columns + pad] and leaves in whole rows below (round 5: as
+                    // 16 two-byte stores per lane and block -- 64-byte half lines -- the 16 MB of this GEMM's output took 8.6 us of a
+                    // 26-us launch, tools/stem_breakdown.sh; lane pairs exchanging values by DPP for 4-byte stores did not change that)
+                    __bf16* const tl = wtile + (cb - cb0) * 32 + col;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float v = acc[r] + bias2;
-                    stem_put(ob + (first ? offa[r] : offa[r] * 4u), first ? __builtin_fmaxf(v, 0.f) : v);
+                    for (int r = 0; r < 16; r++) {
+                        const float v = acc[r] + bias2;
+                        tl[((r & 3) + 8 * (r >> 2) + 4 * hh) * WT_LD] = (__bf16)(first ? __builtin_fmaxf(v, 0.f) : v);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float v = acc[r] + bias2;
+                        stem_put(ob + (first ? offa[r] : offa[r] * 4u), first ? __builtin_fmaxf(v, 0.f) : v);
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; q++) Bc[q] = Bn[q];
+            }
+                    if constexpr (BF) {
+                // the wave's 32 x 160 tile, 16 bytes per lane and store: row = tile row -> its pixel (pixtab; rows past the tile go to the
+                // tensors' slack pixels), 20 units per row -- wave half 0: 8 units of res2a_branch2a's 64 channels, then channels 0..95 of
+                // res2a_branch1; half 1: channels 96..255 -- whole 128-, 192- and 320-byte runs
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own tile: no barrier)
+                const int hf = wave >> 2;
+#pragma unroll 2
+                for (int k = 0; k < 10; k++) {
+                    const int i = lane + 64 * k, row = i / 20, u = i - row * 20;
+                    const f32x4 val = *(const f32x4*)(wtile + row * WT_LD + 8 * u);
+                    const unsigned pe = pixtab[rb * 32 + row];  // element offset of the pixel in the 64-channel tensor
+                    __bf16* dst = (hf == 0 && u < 8) ? (__bf16*)a.pair_out_a + pe + 8 * u
+                                                     : (__bf16*)a.pair_out_b + pe * 4u + (hf == 0 ? 8 * (u - 8) : 96 + 8 * u);
+                    store_wt((f32x4*)dst, val);
+                }
             }
         }
         if (PROF && tid == 0 && blockIdx.x < PROF_WGS) a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
