@@ -65,6 +65,9 @@ __device__ __forceinline__ void put_f32(gfloat* p, float v)
 }
 __device__ __forceinline__ void put_bf16(gbf16* p, float v)
 {
+#if BF16_NOSTORE  // timing probe (make VARIANT=_ns EXTRA=-DBF16_NOSTORE=1; wrong results): what the 2-byte stores of the bf16 epilogues cost
+    return;           // -- up to 31 of 260 us of kernel time per frame (profiles/r05_bf16_store_cost.txt)
+#endif
     const __bf16 b = (__bf16)v;  // round to nearest even
 #if VNECT_AB
     *p = b;
