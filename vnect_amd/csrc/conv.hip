@@ -178,12 +178,30 @@ __device__ __forceinline__ void tail_load_b(const ConvArgs& a, int cb, int lane,
 #pragma unroll
     for (int q = 0; q < NQ; q++) Bf[q] = bp[q * 64];
 }
-// NBLK blocks cb0, cb0 + cbs, ...; PRE: T.rw[0], T.rw[1] (blocks 0, 1) and T.Bf (block 0) were requested by the caller
 // The 64-wide tail's chain (bf16 only, FUSE = 3 on 64x64 tiles): like the wide tail's, the block output tile (64 pixels x 256 channels)
 // is kept in LDS behind the mid tile -- row stride 264 elements -- and the NEXT block's branch2a (1x1, 256 -> 64, ReLU:
 // res2a -> res2b_branch2a, vnect_model.py:44-47) runs on it as a third GEMM (chain_narrow).
 constexpr int NCHAIN_OS = 264;
 constexpr int NCHAIN_OFF = 64 * TAIL_MS<true>;  // bf16 elements from the start of the LDS
+// bf16 64-wide tail: does the launch take the staged form (its output through the LDS tile)?  Uniform, decided by the arguments alone, so
+// every wave of the workgroup agrees and meets at the barrier in front of tail_write_out.
+template <bool BF>
+__device__ __forceinline__ bool tail_staged(const ConvArgs& a)
+{
+    return BF && a.resid != nullptr && a.relu_cols >= 256 && !a.out_f32 && a.Nvalid == 256 && a.tail_n == 256 && (a.ldc & 7) == 0;
+}
+// ... and the write-out: the 64 x 256 bf16 tile, 16 bytes per thread and store, all 512 threads (rows past M go to the tensor's slack)
+__device__ __forceinline__ void tail_write_out(const ConvArgs& a, const float* smem, int m0)
+{
+    const __bf16* tile = (const __bf16*)smem + NCHAIN_OFF;
+    __bf16* out = (__bf16*)a.out + (long long)m0 * a.ldc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = (int)threadIdx.x + 512 * k, row = i >> 5, u = i & 31;
+        store_wt((f32x4*)(out + row * a.ldc + 8 * u), *(const f32x4*)(tile + row * NCHAIN_OS + 8 * u));
+    }
+}
+// NBLK blocks cb0, cb0 + cbs, ...; PRE: T.rw[0], T.rw[1] (blocks 0, 1) and T.Bf (block 0) were requested by the caller
 template <bool BF, int NBLK, bool PRE, bool CH = false>
 __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, int m0, int wm, int cb0, int cbs, int lane, TailRegs<BF>& T)
 {
@@ -228,19 +246,15 @@ __device__ __forceinline__ void tail_gemm(const ConvArgs& a, const float* smem, 
         const unsigned off0 = (unsigned)(mb * a.ldc + n2);
         gfloat* op = (gfloat*)a.out;
         unsigned(&rw)[16] = T.rw[b & 1];
-        if (BF && a.resid && relu2 && !t_of32) {
-            // bf16, the case the network has (a block output: shortcut + ReLU, stored as bf16): four instructions per row, the row base a
-            // scalar pointer (like tail_wide's epilogue: +2.2 % frames/s in bf16, where this code's cold instruction fetch is felt)
-            if (n2 < a.Nvalid) {
-                gbf16* ob = (gbf16*)a.out;
+        if (BF && tail_staged<BF>(a)) {
+            // bf16, the case the network has (a block output: shortcut + ReLU, stored as bf16, all 256 columns valid): the block goes to the
+            // workgroup's OUTPUT TILE in LDS (64 rows x 256 channels behind the mid tile) and leaves from there in whole 512-byte rows
+            // (tail_write_out, round 5) -- as 16 two-byte stores per lane and block, 64-byte half lines, the 13 MB of a 92x92 block output
+            // cost ~3 us of a 10-us launch (profiles/r05_bf16_store_cost.txt).  The chain GEMM (CH) reads the same tile.
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float o = __builtin_fmaxf(acc[r] + bias2 + __builtin_bit_cast(float, rw[r] << 16), 0.f);
-                    put_bf16(ob + off0, o);
-                    ob += ((r & 3) == 3 ? 5 : 1) * a.ldc;
-                    if constexpr (CH)  // (the host chains only behind this case: shortcut + ReLU, bf16 output, all 256 columns valid)
-                        ((__bf16*)smem)[NCHAIN_OFF + (wm * 32 + 4 * hh + (r & 3) + 8 * (r >> 2)) * NCHAIN_OS + n2] = (__bf16)o;
-                }
+            for (int r = 0; r < 16; r++) {
+                const float o = __builtin_fmaxf(acc[r] + bias2 + __builtin_bit_cast(float, rw[r] << 16), 0.f);
+                ((__bf16*)smem)[NCHAIN_OFF + (wm * 32 + 4 * hh + (r & 3) + 8 * (r >> 2)) * NCHAIN_OS + n2] = (__bf16)o;
             }
         } else {
 #pragma unroll
@@ -320,6 +334,24 @@ __device__ __forceinline__ void wide_load_weights(const ConvArgs& a, int tw, int
 // wait for its weight fragments.
 template <bool BF>
 constexpr int CHAIN_DEPTH = BF ? 16 : 8;  // weight groups of the chain GEMM in flight ahead of its MFMAs (registers the tail's own weights free)
+// bf16 wide tail whose output is a block output (shortcut + ReLU, bf16, all 512 columns valid): staged like the 64-wide tail's (tail_staged /
+// tail_write_out) -- the blocks go to the LDS output tile only (32 rows x 512 channels behind the mid tile, where the chain GEMM reads them
+// anyway) and leave in whole 1-KiB rows, 16 bytes per thread and store, behind the barrier all eight tail waves meet at.
+template <bool BF>
+__device__ __forceinline__ bool wide_staged(const ConvArgs& a)
+{
+    return BF && a.resid != nullptr && a.relu_cols >= 512 && !a.out_f32 && a.Nvalid == 512 && a.tail_n == 512 && (a.ldc & 7) == 0;
+}
+__device__ __forceinline__ void wide_write_out(const ConvArgs& a, const float* smem, int m0)
+{
+    const __bf16* tile = (const __bf16*)smem + CHAIN_OFF<true>;
+    __bf16* out = (__bf16*)a.out + (long long)m0 * a.ldc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = (int)threadIdx.x + 512 * k, row = i >> 6, u = i & 63;
+        store_wt((f32x4*)(out + row * a.ldc + 8 * u), *(const f32x4*)(tile + row * CHAIN_OS<true> + 8 * u));
+    }
+}
 // CH: the launch has a chain GEMM behind this tail (chain_gemm below): every block's output also goes to the LDS output tile, and a
 // wave that runs a chain block (cq != nullptr: tail waves 0..3) requests that block's first weight groups BEFORE its stores -- vmcnt
 // counts loads and stores alike on this chip, so loads issued behind the 32 write-through stores could only be waited for together
@@ -394,6 +426,16 @@ __device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, 
                 if constexpr (CH) const_cast<float*>(smem)[CHAIN_OFF<BF> + (4 * hh + (r & 3) + 8 * (r >> 2)) * CHAIN_OS<BF> + n2] = o;
             }
             return;
+        }
+        if constexpr (BF) {
+            if (wide_staged<BF>(a)) {  // (uniform) the block output: to the LDS tile only, wide_write_out stores it
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float o = __builtin_fmaxf(acc[r] + bias2 + __builtin_bit_cast(float, rw[r] << 16), 0.f);
+                    ((__bf16*)smem)[CHAIN_OFF<BF> + (4 * hh + (r & 3) + 8 * (r >> 2)) * CHAIN_OS<BF> + n2] = (__bf16)o;
+                }
+                return;
+            }
         }
         auto rows = [&](auto RESID, auto RELU, auto OUTF32) __attribute__((always_inline)) {
             using OT = typename std::conditional<decltype(OUTF32)::value, gfloat, gbf16>::type;
@@ -502,6 +544,7 @@ __device__ __forceinline__ void chain_narrow(const ConvArgs& a, const float* sme
     const float bias3 = ((cgfloat*)a.chain_bias)[cb * 32 + col];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // all eight tail waves have put their blocks of the output tile into LDS
+    tail_write_out(a, smem, m0);   // this wave's share of the block output (the consumer waves do theirs behind the same barrier)
     const __bf16* at = (const __bf16*)smem + NCHAIN_OFF + (rh * 32 + col) * NCHAIN_OS + 8 * hh;
     f32x16 acc;
 #pragma unroll
@@ -946,11 +989,27 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
                 if constexpr (CHAIN) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();  // all eight tail waves have put their blocks of the output tile into LDS
+                    if constexpr (BF) {
+                        if (wide_staged<BF>(a)) wide_write_out(a, smem, decode(0).m0);
+                    }
                     chain_gemm<BF>(a, smem, decode(0).m0, wave, lane, Cq);
+                } else if constexpr (BF) {
+                    if (wide_staged<BF>(a)) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        wide_write_out(a, smem, decode(0).m0);
+                    }
                 }
             } else {
                 tail_gemm<BF, 3, true, CHAIN>(a, smem, decode(0).m0, wm2, 2 + g2, 2, lane, T);
                 if constexpr (CHAIN) chain_narrow(a, smem, decode(0).m0, wave, lane);
+                else if constexpr (BF) {
+                    if (tail_staged<BF>(a)) {  // (uniform) the block output leaves from the LDS tile: all eight waves, behind one barrier
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        tail_write_out(a, smem, decode(0).m0);
+                    }
+                }
             }
         }
         if constexpr (BONE) {
@@ -1387,16 +1446,32 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
             }
             if constexpr (WIDE) {  // (wm = 0: the tile's 32 rows; the four waves wrote columns 32 wn ..)
                 tail_wide<BF, CHAIN>(a, smem, it.m0, 4 + wave, lane, TWc);
-                if constexpr (CHAIN) {  // the chain GEMM belongs to the producer waves; this wave only delivers its blocks
+                if constexpr (CHAIN) {  // the chain GEMM belongs to the producer waves; this wave delivers its blocks and its share of the write-out
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+                    if constexpr (BF) {
+                        if (wide_staged<BF>(a)) wide_write_out(a, smem, it.m0);
+                    }
+                } else if constexpr (BF) {
+                    if (wide_staged<BF>(a)) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        wide_write_out(a, smem, it.m0);
+                    }
                 }
             } else {
                 TailRegs<BF> T;
                 tail_gemm<BF, 1, false, CHAIN>(a, smem, it.m0, wm2, g2, 0, lane, T);
-                if constexpr (CHAIN) {  // the chain GEMM belongs to the producer waves; this wave only delivers its block
+                if constexpr (CHAIN) {  // the chain GEMM belongs to the producer waves; this wave delivers its block and its share of the write-out
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+                    tail_write_out(a, smem, it.m0);
+                } else if constexpr (BF) {
+                    if (tail_staged<BF>(a)) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        tail_write_out(a, smem, it.m0);
+                    }
                 }
             }
             break;  // one tile per workgroup: nothing of the K-loop state (prefetched fragments, item bookkeeping) lives on
