@@ -1666,14 +1666,21 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     // walked by the same workgroups (VNECT_MAXWG: tuning)
     static const int maxwg_env = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 0;
     const int maxwg = maxwg_env > 0 ? maxwg_env : (KG == 1 && BN <= 64 ? 512 : 256);
-    dim3 grid(a.items < maxwg ? a.items : maxwg);
+    // One workgroup per item also ABOVE two per CU (round 5): the hardware starts the later workgroups as the earlier ones retire, each with the
+    // lean one-item kernel's cold start (~1 us) instead of the streaming kernel's (~2 us) in front of every workgroup's few tiles.  Which launches
+    // gain is a measurement (tools/ab_multi.sh, two calls, profiles/r05_ab_big_grids.txt), three launches of a 3-scale frame are concerned:
+    //   fp32: res3a's projection pair (1 000 tiles of 8 chunks) +0.2 %; res5a's pair (600 tiles of 32 chunks) -1.9 %: short K loops only;
+    //   bf16: both pairs as one-item launches +1.0 % (res3a's alone -0.5 %, res5a's alone +0.3 %): every launch up to 1 024 tiles.
+    static const bool no_one = getenv("VNECT_NO_ONE") != nullptr, no_big = getenv("VNECT_NO_BIG_GRID") != nullptr;  // A/B runs
+    const bool plain64 = KG == 1 && BN <= 64 && maxwg_env <= 0 && !no_big && !a.x3 && !a.pixmode;
+    const bool big_grid = plain64 && (a.bf16 ? a.items <= 1024 : (a.ntaps * a.cpt <= 8 && a.items <= 2048));
+    const bool one = a.ksplit == 1 && !no_one && (a.items <= maxwg || big_grid);
+    dim3 grid(one ? a.items : (a.items < maxwg ? a.items : maxwg));
     const size_t lds = stream_lds<BM, BN, KG, NS>();
     // profiling twin: start / end stamps only, or (VNECT_PROF_DETAIL=1, tools/phase_table.py) the per-phase stamps too
     static const bool detail = getenv("VNECT_PROF_DETAIL") && atoi(getenv("VNECT_PROF_DETAIL")) != 0;
     const int prof = a.prof ? (detail ? 2 : 1) : 0;
-    // one item per workgroup and no K slabs: the kernel without the streaming machinery (conv_stream_kernel, ONE)
-    static const bool no_one = getenv("VNECT_NO_ONE") != nullptr;  // A/B runs
-    const bool one = a.items <= maxwg && a.ksplit == 1 && !no_one;
+    // one item per workgroup and no K slabs (`one`, above): the kernel without the streaming machinery (conv_stream_kernel, ONE)
 #define LAUNCH_STREAM(BF, PR)                                                                                                        \
     do {                                                                                                                             \
         if (one) hipLaunchKernelGGL((conv_stream_kernel<BM, BN, KG, NS, BF, PR, 0, false, false, true>), grid, dim3(512), lds, st, a); \
