@@ -594,10 +594,21 @@ def main():
     # BASELINE.json configs[2] in the same record: the bf16 MFMA conv path, measured exactly like the headline (same frames,
     # same warm-up / steps / barriers), after the fp32 timed region.  N=1 only; never `value`.
     if args.gpus == 1 and args.precision == "fp32" and not args.no_aux and not args.pyramid:
-        hb = make("bf16", use_graph=graph_mode)
+        hb = make("bf16", use_graph=graph_mode, lanes=3)
         for k in range(nslots):
             hb.upload_frame(k, host_frames[k])
         eb, latb = timed(hb, args.steps, args.warmup)
+        barrier()
+        p0 = time.perf_counter()   # the same stream three frames deep on three lanes (as the fp32 handle's pipelined leg)
+        for i in range(args.steps):
+            if i >= 3:
+                hb.collect()
+            clock[0] += 1 / 30
+            hb.submit_resident(i % nslots, clock[0], clock[0] + 1e-3)
+        for _ in range(min(3, args.steps)):
+            hb.collect()
+        torch.cuda.synchronize()
+        bf16_pipelined = args.steps / (time.perf_counter() - p0)
         timb = profile(lambda n: run(hb, n), hb, nprof)
         hb.close()
         out["bf16"] = {"value": round(args.steps / eb, 2), "unit": "frames/s", "ms_per_step": round(eb / args.steps * 1e3, 4),
@@ -605,6 +616,7 @@ def main():
                        "config": "BASELINE.json configs[2]: same frames and scales, bf16 operands / activations, fp32 accumulate, fp32 "
                                  "final maps, f64 post-processing; tolerance-gated against fp32 in tests/test_gpu_bf16.py",
                        "latency_ms": {"p50": round(float(np.percentile(latb, 50)), 4), "p95": round(float(np.percentile(latb, 95)), 4)},
+                       "pipelined_frames_per_s_per_gpu": round(bf16_pipelined, 2),
                        "roofline": roofline(timb, nprof, "bf16")}
 
     # The split-product fp32 path (VNECT_FP32_SPLIT: fp32 tensors and accumulators, fp32-class results -- gated like fp32 in

@@ -547,5 +547,8 @@ def test_bench_line_contract():
         assert r["traffic_source"] and re.match(r"r\d\d%s_traffic\.json$" % pre, r["traffic_source"]), (pre, r["traffic_source"])
         assert r["rocprofv3_source"] and re.match(r"r\d\d%s_conv_roofline\.json$" % pre, r["rocprofv3_source"]), (pre, r["rocprofv3_source"])
     assert d["bf16"]["dtype"] == "bf16" and d["bf16"]["value"] > d["value"] and d["bf16"]["roofline"]["bound"] == "hbm"
+    # every leg says what the same stream does three frames deep, and the call-surface rates sit beside `value` (never above it by much)
+    assert d["bf16"]["pipelined_frames_per_s_per_gpu"] > 0 and d["fp32_split"]["pipelined_frames_per_s_per_gpu"] > 0 and d["pipelined_frames_per_s_per_gpu"] > 0
+    assert 0 < d["pcie_inclusive_frames_per_s_per_gpu"] < 1.02 * d["value"] and 0 < d["pcie_inclusive_from_pinned_capture_buffer_frames_per_s_per_gpu"] < 1.02 * d["value"]
     assert d["fp32_split"]["value"] > 0 and d["fp32_split"]["roofline"]["bound"] == "mfma"
     assert d["rccl_ranks"] == 1 and d["ranks"][0]["device"] == 0 and d["launched_by"] == "single process"
