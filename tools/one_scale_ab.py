@@ -7,7 +7,7 @@ from vnect_amd.weights import synthetic_weights
 W = synthetic_weights()
 for prec, name in ((_native.FP32, "fp32"), (_native.BF16, "bf16")):
     for scales in ([1.0], [1.0, 0.7]):
-        for tag, env in (("default", {}), ("no wide tail", {"VNECT_NO_WIDE_TAIL": "1"}), ("no tails", {"VNECT_NO_TAIL": "1"})):
+        for tag, env in (("default", {}), ("no wide tail", {"VNECT_NO_WIDE_TAIL": "1"}), ("force wide tail", {"VNECT_FORCE_WIDE_TAIL": "1"}), ("no tails", {"VNECT_NO_TAIL": "1"})):
             os.environ.update(env)
             h = _native.Handle(scales, precision=prec)
             h.set_weights(W); h.finalize()

@@ -1579,7 +1579,9 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         // its "stores drained" stamp) puts a store round trip in front of the stamp's own store in every workgroup
         if constexpr (P2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (pstamp) prof[13] = __builtin_amdgcn_s_memrealtime();
-        if (blockIdx.x < PROF_WGS) a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        // (a grid above PROF_WGS -- the one-item launches of more than 512 tiles, round 5 -- shares slots: workgroup id and id + 512 finish a
+        // tile apart, so the later store is the later stamp, which is the one the host's maximum wants)
+        a.prof_end[blockIdx.x & (PROF_WGS - 1)] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 

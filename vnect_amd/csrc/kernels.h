@@ -9,7 +9,7 @@ namespace vnect {
 
 constexpr int MAX_TAPS = 16;
 constexpr int ARG_SLABS_MAX = 32;  // upper bound of the arg-max workgroups per joint (post.hip: ARG_SLABS): what the partials' buffer is sized for
-constexpr int PROF_WGS = 512;   // largest conv grid (two workgroups per CU)
+constexpr int PROF_WGS = 512;   // end-stamp slots per launch (two workgroups per CU; a power of two: larger grids wrap around)
 constexpr int PROF_SLOTS = 24;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
