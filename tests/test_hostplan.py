@@ -373,3 +373,27 @@ def test_hostplan_clean_under_asan_ubsan():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert "passed" in r.stdout and "AddressSanitizer" not in tail and "runtime error" not in tail
+
+
+def test_tile_enumerator_runs_on_the_committed_layer_table():
+    """tools/tile_enum.py (the quantisation argument) on the newest committed layer table: it parses every conv launch,
+    no plan beats the ideal (the launch's blocks over 1 024 SIMDs), the 16-granular search contains the 32-granular one, and the plan in
+    use is never better than the best the enumerator finds by more than the per-tile cost it charges."""
+    import glob
+    import re
+    import subprocess
+    import sys
+    root = ROOT
+    tabs = sorted(glob.glob(os.path.join(root, "profiles", "r0[0-9]_layer_table.txt")))
+    assert tabs, "no committed layer table"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "tile_enum.py"), tabs[-1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if re.match(r"res\d", ln)]
+    assert len(rows) >= 36, len(rows)                      # every conv launch of a three-scale frame behind the stem
+    for ln in rows:
+        f = [x.strip() for x in ln.split("|")]
+        ideal, inuse = (float(x) for x in f[1].split())
+        b32, b16 = float(f[2].split()[-1]), float(f[3].split()[-1])
+        assert ideal <= b16 + 1e-9 and b16 <= b32 + 1e-9, ln   # nothing beats the ideal; the finer search contains the coarser one
+        assert ideal <= inuse + 1e-9, ln
+    assert "upper bound" in r.stdout.splitlines()[-1]
