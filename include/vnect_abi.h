@@ -99,7 +99,10 @@ int vnect_abi_version(void);
  * "conv1/weights" (kh,kw,Cin,Cout), "conv1/biases", "res5c_branch1a/kernel" (kh,kw,Cout,Cin),
  * "bn5c_branch2a/gamma".  Data is copied.  All 109 arrays must be set before vnect_finalize. */
 int vnect_set_weight(vnect_handle* h, const char* name, const float* data, const int64_t* shape, int ndim);
-/* Packs weights into kernel layouts, uploads them, plans buffers, builds the launch sequence.
+/* Packs weights into kernel layouts, uploads them, plans buffers, builds the launch sequence, and warms the handle up on a few grey
+ * frames (so that the first real frame runs at steady-state speed; the filters and frame slots are those of a fresh handle
+ * afterwards).  A launch or device error DURING the warm start is returned (VNECT_E_HIP / VNECT_E_INTERNAL: the plan this handle
+ * would run for every frame is broken); a refused grey frame only skips the warm start and leaves a note in vnect_last_error.
  * (The reference's counterpart is saver.restore, src/estimator.py:55-60.) */
 int vnect_finalize(vnect_handle* h);
 
