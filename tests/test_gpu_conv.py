@@ -30,6 +30,8 @@ def test_conv_stack_every_layer(h3, weights, oracle_net):
     names = [L["name"] for L in h3.layers()]
     acts = ["conv1", "pool1"]
     for n in names:
+        if "[" in n:                          # "<scope>[:N]": the first N channels of a paired launch's layer a as a launch of their own
+            continue                          # (runtime.cpp: head split) -- same tensor, listed with the pair
         if "+" in n:                          # two layers in one launch: "<scope_a>+<rest of scope_b>"
             a, b = n.split("+")
             acts += [a, b if b.startswith("res") else a.split("_")[0] + "_" + b]
@@ -216,6 +218,48 @@ def test_fused_stem_fuzz_frame_shapes_and_scales(weights, monkeypatch):
             assert np.array_equal(fused.activation("res5c_branch2c"), ref.activation("res5c_branch2c")), (scales, H, W)
             assert np.array_equal(a2, b2) and np.array_equal(a3, b3), (scales, H, W)
         fused.close(), ref.close()
+
+
+def test_pair_head_split(weights, oracle_net, monkeypatch):
+    """res5a_branch2a_new + res5a_branch1_new (two 1x1 convs of res4f, vnect_model.py:168-175) at three scales in fp32: 600 tiles of 64 x 64
+    are three rounds over 256 CUs for 2.34 rounds of matrix work, so the first 256 channels of branch2a run as a launch of their own (200
+    tiles of 64 x 32 with two K groups) and the pair keeps 500 tiles (runtime.cpp: add_conv_pair, plan::pair_head_cols).  Both launches
+    write the same tensors: res5a_branch2a_new / res5a_branch1_new within 1e-4 of the oracle; against the single launch
+    (VNECT_NO_HEAD_SPLIT=1) branch1 and channels 256.. of branch2a bit-identical (same tiles, same K order), channels ..255 equal to fp32
+    rounding (two K groups: another summation order); bf16, a split-product handle and one or two scales keep the single launch."""
+    import oracle
+    from tests import helpers
+    n = _native()
+    batch, _, _ = oracle.gen_input_batch(helpers.synth_frame(4321, smooth=True), BASELINE_SCALES)
+    ref = oracle_net.forward(batch)
+    ra, rb = oracle_net.activation("res5a_branch2a_new"), oracle_net.activation("res5a_branch1_new")
+
+    def launches(h):
+        return [(x["name"], x["tile_m"], x["tile_n"], x["workgroups"]) for x in h.layers() if x["name"].startswith("res5a_branch2a_new")]
+
+    keep = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    arena = _handle(BASELINE_SCALES, weights)
+    want = [("res5a_branch2a_new[:256]", 64, 32, 200), ("res5a_branch2a_new+branch1_new", 64, 64, 500)]
+    assert launches(keep) == want and launches(arena) == want, (launches(keep), launches(arena))
+    mk, ma = keep.forward(batch), arena.forward(batch)
+    ka, kb = keep.activation("res5a_branch2a_new"), keep.activation("res5a_branch1_new")
+    assert ka.shape == ra.shape and kb.shape == rb.shape
+    assert float(np.abs(ka - ra).max()) <= 1e-4 * float(np.abs(ra).max()) and float(np.abs(kb - rb).max()) <= 1e-4 * float(np.abs(rb).max())
+    assert np.array_equal(mk, ma) and float(np.abs(ma - ref).max()) <= 1e-4 * float(np.abs(ref).max())
+    monkeypatch.setenv("VNECT_NO_HEAD_SPLIT", "1")
+    one = _handle(BASELINE_SCALES, weights, keep_activations=True)
+    monkeypatch.delenv("VNECT_NO_HEAD_SPLIT")
+    assert launches(one) == [("res5a_branch2a_new+branch1_new", 64, 64, 600)], launches(one)
+    mo = one.forward(batch)
+    oa, ob = one.activation("res5a_branch2a_new"), one.activation("res5a_branch1_new")
+    assert np.array_equal(ob, kb) and np.array_equal(oa[..., 256:], ka[..., 256:])
+    assert float(np.abs(oa - ka).max()) <= 2e-5 * float(np.abs(ra).max()) and float(np.abs(mo - mk).max()) <= 2e-5 * float(np.abs(ref).max())
+    for h in (keep, arena, one):
+        h.close()
+    for kw, scales in ((dict(precision=n.BF16), BASELINE_SCALES), (dict(precision=n.FP32_SPLIT), BASELINE_SCALES), (dict(), [1.0]), (dict(), [1.0, 0.8])):
+        h = _handle(scales, weights, **kw)
+        assert len(launches(h)) == 1, (kw, scales, launches(h))
+        h.close()
 
 
 def test_deconv_three_accumulator_shape(weights, oracle_net, monkeypatch):

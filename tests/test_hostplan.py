@@ -338,6 +338,30 @@ def test_tile_choice_invariants_over_the_whole_network(hp):
     assert list(out) == [64, 32, 2, 1]
 
 
+def test_pair_head_split_only_where_it_saves_a_round(hp):
+    """plan::pair_head_cols: the paired 1x1 launches of the net at 1 .. 6 scales.  Three scales: only res5a's pair (600 tiles of 64x64 = three
+    rounds; 256 head channels as 200 tiles of 64x32x2 + 500 tiles = two and a half) -- and whatever it returns is a shape choose_tile
+    really gives the 64x32x2 K groups in ONE round, fp32 only."""
+    out = (C.c_int * 4)()
+    pairs = {"res3a": (46, 128, 512, 256), "res4a": (23, 256, 1024, 512), "res5a": (23, 512, 1024, 1024), "res2a": (92, 64, 256, 64)}
+    got = {}
+    for S in range(1, 7):
+        for name, (hw, ca, cb, K) in pairs.items():
+            M = S * hw * hw
+            assert hp.hp_pair_head_cols(M, ca, cb, K, 1) == 0
+            c = hp.hp_pair_head_cols(M, ca, cb, K, 0)
+            got[(S, name)] = c
+            if c:
+                assert c % 64 == 0 and 0 < c < ca
+                hp.hp_choose_tile(M, c, 1, K // 32, K, 1, 0, b"head", None, None, out)
+                assert list(out) == [64, 32, 2, 1] and 128 < -(-M // 64) * (c // 32) <= 256
+                rounds = lambda t: -(-t // 256)
+                mt, nt = -(-M // 64), (ca + cb) // 64
+                assert rounds(mt * (nt - c // 64)) + 0.5 < rounds(mt * nt)
+    assert got[(3, "res5a")] == 256
+    assert [k for k, v in got.items() if v and k[0] <= 3] == [(3, "res5a")]
+
+
 def test_stem_row_groups_and_frame_eligibility(hp):
     row0 = (C.c_uint8 * 93)()
     for S in range(1, 9):

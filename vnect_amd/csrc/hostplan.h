@@ -410,6 +410,29 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
     return c;
 }
 
+// ---- head split of a paired 1x1 launch (runtime.cpp: add_conv_pair) -------------------------------------
+// A launch of T 64x64 tiles takes ceil(T / 256) block K loops per SIMD (a CU runs its tiles two at a time on the same four SIMDs); the
+// same columns as 64x32 tiles with two K groups take half a loop per round.  Returns how many leading channels of layer a to run as a
+// launch of their own (a multiple of 64 that choose_tile gives the 64x32x2 shape and ONE round), 0 if that does not beat the single
+// launch by more than it costs: a block K loop is K / 2 matrix instructions of 64 cycles at ~2.15 GHz, a dependent launch ~4 us
+// (floor + cold start).  fp32 only: a bf16 loop is a quarter of that and a launch is not.
+inline int pair_head_cols(int M, int cout_a, int cout_b, int K, bool bf16)
+{
+    if (bf16 || K < 768 || K % 64) return 0;
+    const long long mt = (M + 63) / 64, nt = (cout_a + cout_b) / 64;
+    const double loop_us = K * 0.5 * 64 / 2150.0, launch_us = 4.0;
+    auto rounds = [](long long t) { return (double)((t + 255) / 256); };
+    double best = rounds(mt * nt) * loop_us - 1.0;
+    int head = 0;
+    for (int c = 64; c < cout_a; c += 64) {
+        const long long th = mt * (c / 32);
+        if (mt * (c / 64) > 128 || th <= 128 || th > 256) continue;  // (choose_tile's conditions for 64x32x2)
+        const double t = rounds(mt * (nt - c / 64)) * loop_us + 0.5 * loop_us + launch_us;
+        if (t < best) best = t, head = c;
+    }
+    return head;
+}
+
 // ---- the fused stem's row groups (stem.hip) ------------------------------------------------------------
 // An image's 92 pooled rows in G groups: as MANY tiles (S x G x 4) as one round over the 256 CUs allows (S = 3: G = 21 -> 252 tiles of 4
 // or 5 rows; S = 2: 32 groups of 2 or 3; S = 1: 46 of 2 -- a launch takes as long as its tiles do, so fewer images mean shorter tiles, not

@@ -234,6 +234,7 @@ void hp_choose_tile96(int M, int Nreal, int ntaps, int cpt, int K, int nphase, i
     const plan::TileChoice c = plan::choose_tile(M, Nreal, ntaps, cpt, K, nphase, bf16 != 0, name ? name : "", force, plan_s, true);
     out4[0] = c.BM, out4[1] = c.BN, out4[2] = c.KG, out4[3] = c.ks;
 }
+int hp_pair_head_cols(int M, int cout_a, int cout_b, int K, int bf16) { return plan::pair_head_cols(M, cout_a, cout_b, K, bf16 != 0); }
 int hp_stem_groups(int S, uint8_t* row0) { return plan::stem_groups(S, row0); }
 int hp_stem_frame_fits(const double* scales, int S, int scale_base, int bf16)
 {

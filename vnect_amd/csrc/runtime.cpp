@@ -46,6 +46,7 @@ struct Layer {
     std::string name;
     int in = -1, resid = -1, out = -1, out2 = -1;
     int out3 = -1;  // the chain GEMM's output tensor (the next block's branch2a), or -1
+    int out_col0 = 0;  // first channel of `out` this launch writes (a paired launch whose head columns run as a launch of their own)
     ConvArgs a{};
     ReduceArgs r{};
     int BM = 64, BN = 64, KG = 1;  // tile shape; KG = in-workgroup K groups (conv.hip)
@@ -423,6 +424,13 @@ int add_conv(vnect_handle* h, const ConvSpec& sp)
 // tensors, ReLU per column block.  Used for (i) branch2a (ReLU) + branch1 (none), the two 1x1 convs at the head of a projection
 // block (vnect_model.py:32-35,64-67,106-109,168-175), and (ii) res2b_branch2b + res2c_branch2b, two 3x3 convs that both read
 // res2b_branch2a in the reference's wiring (vnect_model.py:50,56).  Returns the first tensor, *second gets the other one.
+//
+// Head split (round 5): a pair whose 64x64 tiles need one round over the CUs more than their matrix work does -- res5a_branch2a_new +
+// res5a_branch1_new at three scales: 600 tiles = 2.34 per CU = THREE block K loops per SIMD -- runs the first `head` channels of layer a
+// as a launch of their own in a K-group shape (64x32x2: half a K loop per SIMD) and the rest as the pair: 500 tiles = two rounds, 2.5 K
+// loops in all; plan::pair_head_cols weighs that against the extra launch.  Both launches write the same tensors (the pair from channel
+// `head` on: Layer::out_col0); the pair's channels keep their tiles and K order (bit-identical to the single launch), the head's are
+// summed by two K groups like every 64x32x2 layer (equal to fp32 rounding).  VNECT_NO_HEAD_SPLIT=1: A/B runs and the parity test.
 int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std::string& sb, int cout_b, int in,
                   int stride, int* second, int k = 1, bool relu_b = false)
 {
@@ -465,6 +473,28 @@ int add_conv_pair(vnect_handle* h, const std::string& sa, int cout_a, const std:
     plan::pack_conv(Wb->d.data(), k, cin, cout_b, tin.Cs, false, h->bf16, a.K, cout_a, wp);
     for (int n = 0; n < cout_a; n++) bp[n] = Ba->d[n];
     for (int n = 0; n < cout_b; n++) bp[cout_a + n] = Bb->d[n];
+    const int head = (k == 1 && !relu_b && !h->x3 && !getenv("VNECT_NO_HEAD_SPLIT") && !getenv("VNECT_FORCE_TILE"))
+                         ? plan::pair_head_cols(a.M, cout_a, cout_b, a.K, h->bf16) : 0;
+    if (head) {
+        Layer Hd;  // channels [0, head) of layer a: an ordinary 1x1 launch into the same tensor
+        Hd.op = OP_CONV, Hd.name = sa + "[:" + std::to_string(head) + "]", Hd.in = in, Hd.out = L.out;
+        ConvArgs& q = Hd.a;
+        q = a;
+        q.ldc2 = 0, q.split_n = 0, q.relu_cols = head, q.Nvalid = head;
+        Hd.dy[0] = Hd.dx[0] = 0;
+        Hd.Nreal = head, Hd.Kreal = L.Kreal, Hd.flops = 2.0 * a.M * (double)L.Kreal * head;
+        choose_tile(Hd, (long long)a.M);
+        q.Npad = round_up(head, Hd.BN);
+        std::vector<float> wh(wp.begin(), wp.begin() + (size_t)head * a.K), bh(bp.begin(), bp.begin() + head);
+        wh.resize((size_t)q.Npad * a.K, 0.f), bh.resize(q.Npad, 0.f);
+        if (upload_layer_weights(h, Hd, wh) || upload(h, &Hd.bias, bh)) return -1;
+        h->layers.push_back(Hd);
+        // ... and the pair keeps the rest
+        wp.erase(wp.begin(), wp.begin() + (size_t)head * a.K), bp.erase(bp.begin(), bp.begin() + head);
+        L.out_col0 = head, L.Nreal -= head, a.Nvalid = L.Nreal, a.Npad -= head;
+        a.split_n = cout_a - head, a.relu_cols = cout_a - head;
+        L.flops = 2.0 * a.M * (double)L.Kreal * L.Nreal;
+    }
     if (upload_layer_weights(h, L, wp) || upload(h, &L.bias, bp)) return -1;
     if (k == 1 && stride == 1 && cin == 64 && tin.Cs == 64 && cout_a == 64 && cout_b == 256) {
         // res2a_branch2a + res2a_branch1 read pool1: the stem can run them on its pooled tile (setup_stem) and wants the weights in
@@ -575,7 +605,8 @@ int add_conv_tail(vnect_handle* h, const std::string& sb, const std::string& sc,
 void bind_activations(vnect_handle* h, Layer& L)
 {
     ConvArgs& a = L.a;
-    a.in = h->tensors[L.in].d, a.out = h->tensors[L.out].d;
+    a.in = h->tensors[L.in].d;
+    a.out = (float*)((char*)h->tensors[L.out].d + (size_t)L.out_col0 * h->tensors[L.out].esz);
     a.out2 = L.out2 >= 0 ? h->tensors[L.out2].d : nullptr;
     a.chain_out = L.out3 >= 0 ? h->tensors[L.out3].d : nullptr;
     a.resid = L.resid >= 0 ? h->tensors[L.resid].d : nullptr;
