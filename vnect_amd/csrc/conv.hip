@@ -1652,6 +1652,15 @@ constexpr size_t stream_lds() { return (size_t)NS * (BM + BN) * 32 * KG * 4 + (K
 template <int BM, int BN, int KG, int NS>
 constexpr size_t x3_stream_lds() { return (size_t)NS * (BM * 32 + BN * 48) * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
 constexpr int X3_NS = 4;  // 64x64: 4 stages of 20 KiB (the same 80 KB as 5 x 16 KiB: two workgroups per CU)
+// ring depths of the shapes that run ONE workgroup per CU
+#ifndef NS_6432
+#define NS_6432 5
+#endif
+#ifndef NS_32128
+#define NS_32128 5
+#endif
+constexpr int X3_NS_6432 = 5;  // the split-product form of 64x32x2: 5 stages of 28 KiB
+static_assert(stream_lds<64, 32, 2, NS_6432>() <= 160 * 1024 && stream_lds<32, 128, 1, NS_32128>() <= 160 * 1024 && x3_stream_lds<64, 32, 2, X3_NS_6432>() <= 160 * 1024, "one workgroup's ring fits a CU's LDS");
 constexpr size_t x3_lds() { return x3_stream_lds<64, 64, 1, X3_NS>(); }
 
 template <int BM, int BN, int KG, int NS>
@@ -1736,9 +1745,9 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     if constexpr (BM == 64 && BN == 32 && KG == 2) {
         if (a.x3) {  // split-product form of the in-workgroup K-group shape (one workgroup per CU; 5 stages of 28 KiB)
             if (a.bf16 || a.pixmode || a.K % 32 || a.tail_n > 0 || a.bone) return hipErrorInvalidValue;
-            const size_t l3 = x3_stream_lds<64, 32, 2, NS>();
-            if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>), grid, dim3(512), l3, st, a);
-            else hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>), grid, dim3(512), l3, st, a);
+            const size_t l3 = x3_stream_lds<64, 32, 2, X3_NS_6432>();
+            if (prof == 0) hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, X3_NS_6432, false, 0, 0, false, true>), grid, dim3(512), l3, st, a);
+            else hipLaunchKernelGGL((conv_stream_kernel<64, 32, 2, X3_NS_6432, false, 1, 0, false, true>), grid, dim3(512), l3, st, a);
             return hipGetLastError();
         }
     }
@@ -1894,8 +1903,8 @@ static hipError_t setup_stream_rest()
         fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, false, 1, 3>), fns.push_back((const void*)conv_stream_kernel<32, 128, 1, NS, true, 1, 3>);
     }
     if constexpr (BM == 64 && BN == 32 && KG == 2) {
-        for (const void* f : {(const void*)conv_stream_kernel<64, 32, 2, NS, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 32, 2, NS, false, 1, 0, false, true>}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_stream_lds<64, 32, 2, NS>());
+        for (const void* f : {(const void*)conv_stream_kernel<64, 32, 2, X3_NS_6432, false, 0, 0, false, true>, (const void*)conv_stream_kernel<64, 32, 2, X3_NS_6432, false, 1, 0, false, true>}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_stream_lds<64, 32, 2, X3_NS_6432>());
             if (e != hipSuccess) return e;
             e = hipFuncGetAttributes(&fa, f);
             if (e != hipSuccess) return e;
@@ -1924,9 +1933,9 @@ hipError_t conv_setup()
 {
     hipError_t e;
     if ((e = setup_stream<64, 64, 1, 5>()) != hipSuccess) return e;
-    if ((e = setup_stream<64, 32, 2, 5>()) != hipSuccess) return e;
+    if ((e = setup_stream<64, 32, 2, NS_6432>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
-    if ((e = setup_stream<32, 128, 1, 5>()) != hipSuccess) return e;
+    if ((e = setup_stream<32, 128, 1, NS_32128>()) != hipSuccess) return e;
     e = setup_stream<64, 96, 2, 3>();
     g_deconv96 = e == hipSuccess;
     if (e != hipSuccess && e != hipErrorLaunchOutOfResources) return e;  // out of registers: deconv96 unavailable, not an error
@@ -1941,10 +1950,10 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
         return hipErrorInvalidValue;
     // range of the multiply-high divisions in the kernel (x / d exact while x * d < 2^32)
     if ((long long)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1ll << 32) || a.M >= (1 << 24)) return hipErrorInvalidValue;
-    if (KG == 2 && BM == 64 && BN == 32) return launch_stream<64, 32, 2, 5>(a, st);
+    if (KG == 2 && BM == 64 && BN == 32) return launch_stream<64, 32, 2, NS_6432>(a, st);
     if (KG == 4 && BM == 32 && BN == 32) return launch_stream<32, 32, 4, 4>(a, st);
     if (KG == 1 && BM == 64 && BN == 64) return launch_stream<64, 64, 1, 5>(a, st);
-    if (KG == 1 && BM == 32 && BN == 128) return launch_stream<32, 128, 1, 5>(a, st);
+    if (KG == 1 && BM == 32 && BN == 128) return launch_stream<32, 128, 1, NS_32128>(a, st);
     if (KG == 2 && BM == 64 && BN == 96) return g_deconv96 ? launch_stream<64, 96, 2, 3>(a, st) : hipErrorInvalidValue;  // 3 stages of 40 KiB + 24 KiB of partial sums: one workgroup per CU
     return hipErrorInvalidValue;
 }
