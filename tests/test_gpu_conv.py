@@ -260,6 +260,14 @@ def test_pair_head_split(weights, oracle_net, monkeypatch):
         h = _handle(scales, weights, **kw)
         assert len(launches(h)) == 1, (kw, scales, launches(h))
         h.close()
+    # four scales: 816 tiles are four rounds, 128 head channels (136 tiles of 64x32x2) + 748 tiles are three and a half
+    four = [1.0, 0.9, 0.8, 0.7]
+    batch4, _, _ = oracle.gen_input_batch(helpers.synth_frame(4322, smooth=True), four)
+    h = _handle(four, weights)
+    assert [x[:3] for x in launches(h)] == [("res5a_branch2a_new[:128]", 64, 32), ("res5a_branch2a_new+branch1_new", 64, 64)], launches(h)
+    m4, r4 = h.forward(batch4), oracle_net.forward(batch4)
+    h.close()
+    assert float(np.abs(m4 - r4).max()) <= 1e-4 * float(np.abs(r4).max())
 
 
 def test_deconv_three_accumulator_shape(weights, oracle_net, monkeypatch):
