@@ -598,7 +598,7 @@ __device__ __forceinline__ void chain_narrow(const ConvArgs& a, const float* sme
 // split offline (hostplan.h: pack_split3) and land as three 64-byte planes per row and chunk -- 20 KiB per stage instead of 16, so the
 // ring has 4 stages in the same 80 KB.  Results differ from the fp32 instruction's in the last bits only (summation order, the dropped
 // terms); the parity gates are the fp32 path's.
-// ONE (round 5): the launch has exactly one work item per workgroup and no cross-workgroup K split (grid == items, ksplit == 1: 35 of the 38
+// ONE (round 5): the launch has exactly one work item per workgroup and no cross-workgroup K split (grid == items, ksplit == 1: 36 of the 39
 // conv launches of a three-scale frame; the launcher checks) -- the streaming machinery (item count, stride, the next item's set-up inside
 // the issue path, K slices) is compiled OUT of such a launch's kernel.  A launch's cold start is ~750 one-off instructions in front of the
 // first DMA, issued at one per ~4 cycles by a single wave (profiles/r04_phase_producer_start.txt): what is not there is not issued.  Every
