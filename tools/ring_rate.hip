@@ -12,7 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLDS16(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 typedef __attribute__((address_space(3))) void* ldsp;
 
-constexpr int NS = 5;
+#ifndef RING_NS
+#define RING_NS 5
+#endif
+constexpr int NS = RING_NS;
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -22,12 +25,12 @@ struct P {
     float* out;
     long long* res;      // per WG: {cycles, realtime ticks}
     int chunks, kwin, share, mfma, reads;
-    int lfirst, cons_waves, m16, lprio, cprio;  // first active loader wave; consumer waves that compute; 16x16x4 MFMAs; priorities
+    int lfirst, cons_waves, m16, lprio, cprio, two_acc;  // first active loader wave; consumer waves that compute; 16x16x4 MFMAs; priorities
 };
 
 // MODE 0: global_load_lds (64-bit addresses); 1: buffer_load offen lds (voffset + scalar chunk offset); 2: MODE 0 without swizzle
 // LW: loader waves (1, 2, 4); each chunk = 16 wave-instructions of 1 KiB, LW waves issue 16/LW each
-template <int MODE, int LW, int NM, int M16, int RD, int SCHED, int PCS>
+template <int MODE, int LW, int NM, int M16, int RD, int SCHED, int PCS, int TWO>
 __global__ __launch_bounds__(512, 4) void ring(const P p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         const int lw = wave - p.lfirst;
         if (lw < 0 || lw >= LW) {  // idle loader waves still take part in the barriers
             __builtin_amdgcn_s_barrier();
-            for (int g = 0; g < G; g++) __builtin_amdgcn_s_barrier();
+            for (int g = 0; g < (SCHED == 4 ? G / 2 : G); g++) __builtin_amdgcn_s_barrier();
             return;
         }
         if (p.lprio) __builtin_amdgcn_s_setprio(3);
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
                 case 1: wait_vm<PER>(); break;
                 case 2: wait_vm<2 * PER>(); break;
                 case 3: wait_vm<(3 * PER > 63 ? 63 : 3 * PER)>(); break;
-                default: wait_vm<0>(); break;
+                case 4: wait_vm<(4 * PER > 63 ? 63 : 4 * PER)>(); break;
+                case 5: wait_vm<(5 * PER > 63 ? 63 : 5 * PER)>(); break;
+                case 0: wait_vm<0>(); break;
+                default: if (young > 5) wait_vm<(5 * PER > 63 ? 63 : 5 * PER)>(); else wait_vm<0>(); break;
             }
         };
         t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -125,6 +131,33 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
             }
             return;
         }
+        if constexpr (SCHED == 4) {
+            // TWO chunks per barrier (round 5 probe): barrier P opens chunks 2P, 2P + 1; the consumers prefetch chunk 2P + 2's fragments behind
+            // chunk 2P + 1's MFMAs, so chunks <= 2P + 2 must have landed at barrier P; behind it the stages of chunks 2P - 2, 2P - 1 are refilled
+            // with chunks 2P - 2 + NS, 2P - 1 + NS.  G even.
+            int issued = 0;
+            auto put = [&]() __attribute__((always_inline)) { issue(issued % NS); issued++; };
+            for (int q = 0; q < NS - 2 && q < G; q++) put();  // chunks 0 .. NS - 3 before barrier 0 (stages NS - 2, NS - 1 play "chunks -2, -1")
+            // landed(c): at most (issued - 1 - c) chunks younger than c may be in flight
+            auto need = [&](int c) __attribute__((always_inline)) {
+                const int young = issued - 1 - (c < G - 1 ? c : G - 1);
+                wait_landed(young < 0 ? 0 : young);
+            };
+            need(2);
+            __builtin_amdgcn_s_barrier();  // barrier 0
+            for (int P2 = 0; P2 < G / 2; P2++) {
+                // behind barrier P: refill
+                if (issued < G) put();
+                if (issued < G) put();
+                need(2 * (P2 + 1) + 2);
+                __builtin_amdgcn_s_barrier();  // barrier P + 1
+            }
+            if (threadIdx.x == 256) {
+                p.res[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0;
+                p.res[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NS - 1; q++)
             if (q < G) issue(q);
@@ -147,7 +180,7 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     // consumers
     if (wave >= p.cons_waves) {
         __builtin_amdgcn_s_barrier();
-        for (int g = 0; g < G; g++) __builtin_amdgcn_s_barrier();
+        for (int g = 0; g < (SCHED == 4 ? G / 2 : G); g++) __builtin_amdgcn_s_barrier();
         return;
     }
     if (p.cprio) __builtin_amdgcn_s_setprio(3);
@@ -160,9 +193,9 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     for (int q = 0; q < 4; q++) fo[q] = (lane & 31) * 32 + (((2 * q + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4);
     struct Frag { f32x4 a[4], b[4]; };
     Frag F0, F1;
-    f32x16 acc;
+    f32x16 acc, accb;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f, accb[r] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; q++) F0.a[q] = F0.b[q] = F1.a[q] = F1.b[q] = f32x4{1.f, 2.f, 3.f, 4.f};
     int stage = 0;
@@ -171,15 +204,17 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         if (M16) {                                                                                       \
             c4[(e & 1) * 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c4[(e & 1) * 2], 0, 0, 0);         \
             c4[(e & 1) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, c4[(e & 1) * 2 + 1], 0, 0, 0); \
-        } else                                                                                           \
+        } else if (TWO && ((e) & 1))                                                               \
+            accb = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, accb, 0, 0, 0);                            \
+        else                                                                                             \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);                              \
     } while (0)
     auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
         if constexpr (SCHED >= 1) {
             // barrier first, then the 16 MFMAs of this chunk with the 8 reads of the next one behind every second MFMA (SCHED 1)
-            // or behind MFMAs 0-7 (SCHED 2) or 4-11 (SCHED 3)
-            __builtin_amdgcn_s_barrier();
+            // or behind MFMAs 0-7 (SCHED 2) or 4-11 (SCHED 3); SCHED 4: as 1, the barrier is the caller's (every second chunk)
+            if constexpr (SCHED != 4) __builtin_amdgcn_s_barrier();
             const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
             const float* Bb = smem + nstage * STAGE + (64 + wn * 32) * 32;
 #pragma unroll
@@ -188,11 +223,11 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
                 for (int e = 0; e < 4; e++) {
                     const int i = q * 4 + e;
                     MMA(cur.a[q][e], cur.b[q][e], e);
-                    const int r = SCHED == 1 ? (i & 1 ? i >> 1 : -1) : SCHED == 2 ? (i < 8 ? i : -1) : (i >= 4 && i < 12 ? i - 4 : -1);
+                    const int r = (SCHED == 1 || SCHED == 4) ? (i & 1 ? i >> 1 : -1) : SCHED == 2 ? (i < 8 ? i : -1) : (i >= 4 && i < 12 ? i - 4 : -1);
                     if (r >= 0) {
                         if (r & 1) nxt.b[r >> 1] = *(const f32x4*)(Bb + fo[r >> 1]);
                         else nxt.a[r >> 1] = *(const f32x4*)(Ab + fo[r >> 1]);
-                        __builtin_amdgcn_sched_group_barrier(0x008, SCHED == 1 ? 2 : 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, (SCHED == 1 || SCHED == 4) ? 2 : 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
@@ -225,22 +260,29 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         stage = nstage;
     };
     __builtin_amdgcn_s_barrier();
+    if constexpr (SCHED == 4) {
+        for (int g = 0; g < G; g += 2) {  // barrier 0 (above) opened chunks 0, 1 (and 2 for the prefetch)
+            step(F0, F1);
+            step(F1, F0);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else
     for (int g = 0; g < G; g += 2) {
         step(F0, F1);
         if (g + 1 < G) step(F1, F0);
     }
     float s = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) s += acc[r] + c4[r & 3][r >> 2];
+    for (int r = 0; r < 16; r++) s += acc[r] + accb[r] + c4[r & 3][r >> 2];
     p.out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
-template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1, int SCHED = 0, int PCS = 16>
+template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1, int SCHED = 0, int PCS = 16, int TWO = 0>
 void run(const char* name, P p, int grid)
 {
-    hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD, SCHED, PCS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * PCS * 1024);
+    hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD, SCHED, PCS, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * PCS * 1024);
     for (int rep = 0; rep < 3; rep++) {
-        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED, PCS>), dim3(grid), dim3(512), NS * PCS * 1024, 0, p);
+        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED, PCS, TWO>), dim3(grid), dim3(512), NS * PCS * 1024, 0, p);
         hipDeviceSynchronize();
     }
     std::vector<long long> h(grid * 2);
@@ -269,12 +311,20 @@ int main()
     hipMalloc(&res, 512 * 16);
     p.a = a, p.b = b, p.out = out, p.res = res, p.chunks = 510, p.kwin = kwin;
     p.share = 4, p.reads = 1, p.mfma = 16;
+    p.two_acc = 0;
     auto cfg = [&](int lfirst, int cons, int lprio, int cprio) { p.lfirst = lfirst, p.cons_waves = cons, p.m16 = 0, p.lprio = lprio, p.cprio = cprio; };
     for (int grid : {200, 256}) {
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1>("16 KiB stages (64x64 tile)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24>("24 KiB stages (64x32 tile x 2 K groups)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 0, 0, 1, 1, 24>("24 KiB stages, no MFMA", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 32>("32 KiB stages (32x32 x 4 K groups / 64x64 x 2)", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 16, 1>("16 KiB stages, two accumulator chains", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24, 1>("24 KiB stages, two accumulator chains", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 4, 24, 1>("24 KiB, two chains, TWO chunks per barrier", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 4>("16 KiB stages, TWO chunks per barrier", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 4, 24>("24 KiB stages, TWO chunks per barrier", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 4, 20>("20 KiB stages, TWO chunks per barrier", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 20>("20 KiB stages (32x128 tile)", p, grid);
     }
     return 0;
 }
