@@ -318,6 +318,8 @@ int main()
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24>("24 KiB stages (64x32 tile x 2 K groups)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 0, 0, 1, 1, 24>("24 KiB stages, no MFMA", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 32>("32 KiB stages (32x32 x 4 K groups / 64x64 x 2)", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 0>("16 KiB, barrier behind MFMA 8, reads behind 8-15", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0, 0>("16 KiB, the same without the fragment reads", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 16, 1>("16 KiB stages, two accumulator chains", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24, 1>("24 KiB stages, two accumulator chains", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 4, 24, 1>("24 KiB, two chains, TWO chunks per barrier", p, grid);
