@@ -209,6 +209,45 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         else                                                                                             \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);                              \
     } while (0)
+    // SCHED 6 (round 5 probe): the B fragments come straight from global memory / L2 -- three chunks ahead, in registers -- and only the 4 A
+    // fragments are read from LDS: half the ds_read_b128 per step, 4 global_load_dwordx4 instead
+    f32x4 Bg[3][4];
+    typedef __attribute__((address_space(1))) const f32x4 cgf4;
+    cgf4* bsrc = (cgf4*)(p.b + (size_t)(wn * 32 + (lane & 31)) * p.kwin * 32 + (lane >> 5) * 4);
+    int bcc = 0;
+    auto ldB = [&](f32x4(&R)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) R[q] = bsrc[bcc * 8 + 2 * q];
+        if (++bcc == p.kwin) bcc = 0;
+    };
+    if constexpr (SCHED == 6) ldB(Bg[0]), ldB(Bg[1]), ldB(Bg[2]);
+    auto step6 = [&](Frag& cur, Frag& nxt, f32x4(&Bcur)[4]) __attribute__((always_inline)) {
+        const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        __builtin_amdgcn_s_barrier();
+        const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
+        f32x4 Bn[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = q * 4 + e;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], Bcur[q][e], acc, 0, 0, 0);
+                if ((i & 3) == 1) {
+                    nxt.a[i >> 2] = *(const f32x4*)(Ab + fo[i >> 2]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                } else if ((i & 3) == 3) {
+                    Bn[i >> 2] = bsrc[bcc * 8 + 2 * (i >> 2)];
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one VMEM read
+                }
+            }
+        if (++bcc == p.kwin) bcc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) Bcur[q] = Bn[q];  // (the slot just consumed takes the chunk three ahead)
+        __builtin_amdgcn_sched_barrier(0);
+        stage = nstage;
+    };
     auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
         const int nstage = stage + 1 == NS ? 0 : stage + 1;
         if constexpr (SCHED >= 1) {
@@ -260,6 +299,14 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         stage = nstage;
     };
     __builtin_amdgcn_s_barrier();
+    if constexpr (SCHED == 6) {
+        for (int g = 0; g < G; g += 6) {  // G is a multiple of 6
+            step6(F0, F1, Bg[0]), step6(F1, F0, Bg[1]), step6(F0, F1, Bg[2]);
+            step6(F1, F0, Bg[0]), step6(F0, F1, Bg[1]), step6(F1, F0, Bg[2]);
+        }
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < 4; q++) acc[0] += Bg[k][q][0];
+    } else
     if constexpr (SCHED == 4) {
         for (int g = 0; g < G; g += 2) {  // barrier 0 (above) opened chunks 0, 1 (and 2 for the prefetch)
             step(F0, F1);
@@ -320,6 +367,8 @@ int main()
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 32>("32 KiB stages (32x32 x 4 K groups / 64x64 x 2)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 0>("16 KiB, barrier behind MFMA 8, reads behind 8-15", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0, 0>("16 KiB, the same without the fragment reads", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 6>("16 KiB stages, B fragments from L2 (4 LDS + 4 global reads)", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 6, 24>("24 KiB stages, B fragments from L2", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 16, 1>("16 KiB stages, two accumulator chains", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24, 1>("24 KiB stages, two accumulator chains", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 4, 24, 1>("24 KiB, two chains, TWO chunks per barrier", p, grid);
