@@ -367,6 +367,9 @@ int main()
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 32>("32 KiB stages (32x32 x 4 K groups / 64x64 x 2)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 0>("16 KiB, barrier behind MFMA 8, reads behind 8-15", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0, 0>("16 KiB, the same without the fragment reads", p, grid);
+        cfg(0, 4, 0, 0); run<1, 4, 16, 0, 1, 1>("16 KiB stages, no priorities", p, grid);
+        cfg(0, 4, 0, 1); run<1, 4, 16, 0, 1, 1>("16 KiB stages, consumers at priority 3", p, grid);
+        cfg(0, 4, 0, 1); run<1, 4, 16, 0, 1, 1, 24>("24 KiB stages, consumers at priority 3", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 6>("16 KiB stages, B fragments from L2 (4 LDS + 4 global reads)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 6, 24>("24 KiB stages, B fragments from L2", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 16, 1>("16 KiB stages, two accumulator chains", p, grid);
