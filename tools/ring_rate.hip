@@ -31,11 +31,12 @@ struct P {
 // MODE 0: global_load_lds (64-bit addresses); 1: buffer_load offen lds (voffset + scalar chunk offset); 2: MODE 0 without swizzle
 // LW: loader waves (1, 2, 4); each chunk = 16 wave-instructions of 1 KiB, LW waves issue 16/LW each
 template <int MODE, int LW, int NM, int M16, int RD, int SCHED, int PCS, int TWO>
-__global__ __launch_bounds__(512, 4) void ring(const P p)
+__global__ __launch_bounds__(SCHED == 7 ? 768 : 512) void ring(const P p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    constexpr int CT = SCHED == 7 ? 512 : 256;  // consumer threads (SCHED 7: EIGHT consumer waves, two per SIMD, each on half of a chunk's K)
+    const int tid = threadIdx.x >= CT ? threadIdx.x - CT : threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= CT;
     const int G = p.chunks;
     constexpr int PER = PCS / LW;  // DMA instructions per loader wave per chunk
     constexpr int STAGE = PCS * 256;  // floats per stage
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
             };
             for (int g = 0; g < G; g += 3) body(R0, R1), body(R1, R2), body(R2, R0);  // G is a multiple of 6
             wait_vm<0>();
-            if (threadIdx.x == 256) {
+            if (threadIdx.x == CT) {
                 p.res[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0;
                 p.res[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
             }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
                 need(2 * (P2 + 1) + 2);
                 __builtin_amdgcn_s_barrier();  // barrier P + 1
             }
-            if (threadIdx.x == 256) {
+            if (threadIdx.x == CT) {
                 p.res[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0;
                 p.res[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
             }
@@ -171,14 +172,14 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
             if (g + NS - 1 < G) issue(stage == 0 ? NS - 1 : stage - 1);
             stage = stage + 1 == NS ? 0 : stage + 1;
         }
-        if (threadIdx.x == 256) {
+        if (threadIdx.x == CT) {
             p.res[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0;
             p.res[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
         }
         return;
     }
     // consumers
-    if (wave >= p.cons_waves) {
+    if (SCHED != 7 && wave >= p.cons_waves) {
         __builtin_amdgcn_s_barrier();
         for (int g = 0; g < (SCHED == 4 ? G / 2 : G); g++) __builtin_amdgcn_s_barrier();
         return;
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     f32x4 c4[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) c4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int wm = wave >> 1, wn = wave & 1;
+    const int sub = SCHED == 7 ? wave >> 2 : 0;  // SCHED 7: K half of the chunk (fragments 2 sub, 2 sub + 1)
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
     int fo[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) fo[q] = (lane & 31) * 32 + (((2 * q + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4);
@@ -204,7 +206,9 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         if (M16) {                                                                                       \
             c4[(e & 1) * 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c4[(e & 1) * 2], 0, 0, 0);         \
             c4[(e & 1) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, c4[(e & 1) * 2 + 1], 0, 0, 0); \
-        } else if (TWO && ((e) & 1))                                                               \
+        } else if (TWO == 2)                                                                             \
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));            \
+        else if (TWO && ((e) & 1))                                                               \
             accb = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, accb, 0, 0, 0);                            \
         else                                                                                             \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);                              \
@@ -245,6 +249,28 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         if (++bcc == p.kwin) bcc = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) Bcur[q] = Bn[q];  // (the slot just consumed takes the chunk three ahead)
+        __builtin_amdgcn_sched_barrier(0);
+        stage = nstage;
+    };
+    auto step7 = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
+        // eight consumer waves: this one takes fragments q = 2 sub, 2 sub + 1 of its block (16 of the chunk's 32 k): 8 MFMAs, 4 reads
+        const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        __builtin_amdgcn_s_barrier();
+        const float* Ab = smem + nstage * STAGE + (wm * 32) * 32;
+        const float* Bb = smem + nstage * STAGE + (64 + wn * 32) * 32;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[q][e], cur.b[q][e], acc, 0, 0, 0);
+                if (e & 1) {
+                    const int r = q * 2 + (e >> 1);  // 0..3
+                    if (r & 1) nxt.b[r >> 1] = *(const f32x4*)(Bb + (sub ? fo[2 + (r >> 1)] : fo[r >> 1]));
+                    else nxt.a[r >> 1] = *(const f32x4*)(Ab + (sub ? fo[2 + (r >> 1)] : fo[r >> 1]));
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
         __builtin_amdgcn_sched_barrier(0);
         stage = nstage;
     };
@@ -299,6 +325,12 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
         stage = nstage;
     };
     __builtin_amdgcn_s_barrier();
+    if constexpr (SCHED == 7) {
+        for (int g = 0; g < G; g += 2) {
+            step7(F0, F1);
+            step7(F1, F0);
+        }
+    } else
     if constexpr (SCHED == 6) {
         for (int g = 0; g < G; g += 6) {  // G is a multiple of 6
             step6(F0, F1, Bg[0]), step6(F1, F0, Bg[1]), step6(F0, F1, Bg[2]);
@@ -321,7 +353,7 @@ __global__ __launch_bounds__(512, 4) void ring(const P p)
     float s = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) s += acc[r] + accb[r] + c4[r & 3][r >> 2];
-    p.out[(size_t)blockIdx.x * 256 + tid] = s;
+    p.out[(size_t)blockIdx.x * 256 + (tid & 255)] = s;
 }
 
 template <int MODE, int LW, int NM = 16, int M16 = 0, int RD = 1, int SCHED = 0, int PCS = 16, int TWO = 0>
@@ -329,7 +361,7 @@ void run(const char* name, P p, int grid)
 {
     hipFuncSetAttribute((const void*)ring<MODE, LW, NM, M16, RD, SCHED, PCS, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * PCS * 1024);
     for (int rep = 0; rep < 3; rep++) {
-        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED, PCS, TWO>), dim3(grid), dim3(512), NS * PCS * 1024, 0, p);
+        hipLaunchKernelGGL((ring<MODE, LW, NM, M16, RD, SCHED, PCS, TWO>), dim3(grid), dim3(SCHED == 7 ? 768 : 512), NS * PCS * 1024, 0, p);
         hipDeviceSynchronize();
     }
     std::vector<long long> h(grid * 2);
@@ -367,6 +399,11 @@ int main()
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 32>("32 KiB stages (32x32 x 4 K groups / 64x64 x 2)", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 0>("16 KiB, barrier behind MFMA 8, reads behind 8-15", p, grid);
         cfg(0, 4, 1, 0); run<1, 4, 16, 0, 0, 0>("16 KiB, the same without the fragment reads", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 16, 2>("16 KiB stages, accumulator in AGPRs (asm)", p, grid);
+        cfg(0, 4, 1, 0); run<1, 4, 16, 0, 1, 1, 24, 2>("24 KiB stages, accumulator in AGPRs (asm)", p, grid);
+        cfg(0, 8, 1, 0); run<1, 4, 16, 0, 1, 7>("16 KiB stages, EIGHT consumer waves (8 MFMAs + 4 reads each)", p, grid);
+        cfg(0, 8, 1, 0); run<1, 4, 16, 0, 1, 7, 24>("24 KiB stages, EIGHT consumer waves", p, grid);
+        cfg(0, 8, 1, 0); run<1, 4, 16, 0, 1, 7, 20>("20 KiB stages, EIGHT consumer waves", p, grid);
         cfg(0, 4, 0, 0); run<1, 4, 16, 0, 1, 1>("16 KiB stages, no priorities", p, grid);
         cfg(0, 4, 0, 1); run<1, 4, 16, 0, 1, 1>("16 KiB stages, consumers at priority 3", p, grid);
         cfg(0, 4, 0, 1); run<1, 4, 16, 0, 1, 1, 24>("24 KiB stages, consumers at priority 3", p, grid);
