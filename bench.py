@@ -194,6 +194,19 @@ def roofline(tim, nprof, precision, images_frac=1.0):
                 **common)
 
 
+def latency_summary(lat, steps):
+    """p50 / p95 / max of the per-frame latencies of a timed region, the rate the MEDIAN frame gives (a short run's mean is moved by
+    one slow frame: `value` stays the contract's mean, this is the self-check beside it), and -- for runs short enough to print --
+    the frames themselves in order, so that a slow frame can be located (first after the barrier? periodic?) from the line alone."""
+    import numpy as np
+    p50 = float(np.percentile(lat, 50))
+    d = {"p50": round(p50, 4), "p95": round(float(np.percentile(lat, 95)), 4), "max": round(float(lat.max()), 4),
+         "value_from_median": round(1e3 / p50, 2)}
+    if steps <= 64:
+        d["frames_ms"] = [round(float(x), 4) for x in lat]
+    return d
+
+
 def profile(run, h, n):
     """n frames on the profiling twin of the frame graph; `run(n)` drives them (every rank of a pyramid job takes part)."""
     h.set_profiling(True)
@@ -292,6 +305,12 @@ def main():
                     help="parity evidence for the N > 1 tests (tests/test_gpu_multigpu.py): behind the timed region every rank runs 8 more "
                          "frames of its stream on fresh filter banks at fixed timestamps and writes PREFIX.<leg>.rank<r>.npz (j2, j3); a "
                          "single-GPU run of the same seeds must reproduce them bit for bit")
+    ap.add_argument("--no-bind", action="store_true",
+                    help="N > 1: leave every rank's host thread where the scheduler puts it.  Default: before its first GPU call a rank binds "
+                         "itself to the cores local to its GPU (/sys/bus/pci/devices/<bdf>/local_cpulist) and reports the mask in `ranks[]`")
+    ap.add_argument("--bind", action="store_true", help="apply the same binding at N = 1 (default there: report it, do not apply it)")
+    ap.add_argument("--no-n1", action="store_true",
+                    help="N > 1: skip the same-job N = 1 reference (rank 0's loop run alone, the other ranks idle, before the N-rank region)")
     ap.add_argument("--pyramid-both", action="store_true",
                     help="--pyramid with BOTH exchange forms in one job (rccl first, then p2p): the side-by-side SURVEY 8e asks for "
                          "from one 3-GPU lease; `value` is the RCCL all-gather form (the one north_star names), p2p under \"pyramid_p2p\"")
@@ -310,6 +329,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world  # the launcher's word counts
+
+    # Host placement FIRST, before this process imports torch or loads the HIP library (their helper threads and pinned allocations
+    # inherit the mask): the cores local to this rank's GPU.  sysfs only, no GPU call (vnect_amd/parallel.py).
+    from vnect_amd.parallel import bind_rank
+    _dev_env = os.environ.get("VNECT_BENCH_DEVICE")
+    _want_dev = int(_dev_env if _dev_env is not None else os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.bind:
+        binding = bind_rank(_want_dev, enable=not args.no_bind)
+    else:
+        binding = bind_rank(_want_dev, enable=False)
+        binding["reason"] = "N = 1: reported, not applied (--bind applies it)"
 
     # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to STDOUT when its first communicator
     # is made (torch's "nccl" process group in an N > 1 run, the library's in a pyramid run).  So file descriptor 1 points at stderr while
@@ -348,7 +378,12 @@ def main():
         pci = torch.cuda.get_device_properties(local_rank).pci_bus_id
     except Exception:
         pci = None
-    placement = grp.all_gather_object({"rank": rank, "device": local_rank, "pci_bus_id": pci, "pid": os.getpid()})
+    if binding.get("bdf") and pci is not None:   # the sysfs chain (KFD node order) and HIP agree on which device this is?
+        try:
+            binding["bdf_is_the_hip_device"] = int(binding["bdf"].split(":")[1], 16) == int(pci)
+        except (ValueError, IndexError):
+            pass
+    placement = grp.all_gather_object({"rank": rank, "device": local_rank, "pci_bus_id": pci, "pid": os.getpid(), "host_binding": binding})
     weights = synthetic_weights()
     nslots = 8
 
@@ -410,6 +445,8 @@ def main():
         grp.barrier()
         torch.cuda.synchronize()
 
+    own = [0.0]
+
     def timed(hh, steps, warmup):
         """W untimed frames, then EXACTLY `steps` synchronous frames between barrier + synchronize; MAX over ranks."""
         run(hh, warmup)
@@ -420,6 +457,7 @@ def main():
             clock[0] += 1 / 30
             j2, j3 = hh.infer_resident(i % nslots, clock[0], clock[0] + 1e-3)
             stamps.append(time.perf_counter())  # per-frame latency distribution (median + p95)
+        own[0] = stamps[-1] - t0    # this rank's own time for its K frames (before it waits for the others)
         barrier()
         elapsed = grp.max_over_ranks(time.perf_counter() - t0)
         assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
@@ -436,7 +474,41 @@ def main():
         np.savez("%s.%s.rank%d.npz" % (args.dump_joints, leg, rank), j2=np.stack([a for a, _ in js]), j3=np.stack([b for _, b in js]),
                  device=np.int64(local_rank), stream=np.int64(stream))
 
+    # N > 1: the same-box, same-minute denominator of `value / N` -- rank 0 runs the N = 1 loop ALONE first (W warm-up + K timed frames of
+    # the plain 3-scale handle; a pyramid job builds one for this), the other ranks wait on the rendezvous store with their GPUs idle.
+    n1_same_job = None
+    if args.gpus > 1 and not args.no_n1:
+        grp.barrier()
+        if rank == 0:
+            h1 = h
+            if args.pyramid:
+                h1 = make(args.precision, use_graph=graph_mode)
+                for k in range(nslots):
+                    h1.upload_frame(k, host_frames[k])
+            run(h1, args.warmup)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st1 = [t0]
+            for i in range(args.steps):
+                clock[0] += 1 / 30
+                h1.infer_resident(i % nslots, clock[0], clock[0] + 1e-3)
+                st1.append(time.perf_counter())
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t0
+            n1_same_job = {"value": round(args.steps / e1, 2), "unit": "frames/s", "ms_per_step": round(e1 / args.steps * 1e3, 4),
+                           "steps": args.steps, "warmup": args.warmup, "rank": 0, "device": local_rank,
+                           "latency_ms": latency_summary(np.diff(np.array(st1)) * 1e3, args.steps),
+                           "what": "rank 0's synchronous 3-scale loop run alone inside this job, before the %d-rank region; the other ranks "
+                                   "wait on the rendezvous store (host-side: their GPUs are idle)" % args.gpus}
+            if args.pyramid:
+                h1.close()
+            else:
+                h.reset_filters()
+        grp.host_handoff("n1_done", release=rank == 0)
+        grp.barrier()
+
     elapsed, lat = timed(h, args.steps, args.warmup)
+    own_elapsed = own[0]
     dump_joints(h, ("pyramid_" + args.exchange) if args.pyramid else "replica")
 
     # pipelined rate of the same stream (three frames in flight on three lanes: they overlap, only the filter kernels stay
@@ -525,9 +597,20 @@ def main():
         h.reset_filters()
 
     nprof = min(max(args.steps // 4, 10), 100)
-    tim = None
-    if rank == 0 or args.pyramid:  # pyramid: every inference contains the exchange, so every rank must take part
-        tim = profile(lambda n: run(h, n), h, nprof)
+    # every rank profiles its own handle (no collective inside a replica's frames; a pyramid job's inferences contain the exchange, so
+    # every rank must take part anyway): per-rank conv-stack time and the shader clock each GPU held are what explains an N > 1 curve
+    def rank_report(lat_, own_, tim_):
+        return grp.all_gather_object({
+            "rank": rank, "device": local_rank,
+            "frames_per_s": round(args.steps / own_, 2), "own_elapsed_s": round(own_, 5),
+            "latency_ms": {k: v for k, v in latency_summary(lat_, args.steps).items() if k != "frames_ms"},
+            "conv_stack_ms": round(tim_["conv_slot_ms"] / nprof, 4), "conv_first_to_last_ms": round(tim_["net_ms"] / nprof, 4),
+            "frame_ms_hip_events": round(tim_["total_ms"] / nprof, 4),
+            "shader_clock_mhz": None if not tim_.get("shader_clock_mhz") else round(tim_["shader_clock_mhz"], 1),
+            "host_binding": {k: binding.get(k) for k in ("bound", "affinity", "n_cpus", "numa_node", "bdf", "reason") if binding.get(k) is not None}})
+
+    tim = profile(lambda n: run(h, n), h, nprof)
+    per_rank = rank_report(lat, own_elapsed, tim)
     pyramid_p2p = None
     if args.pyramid_both:  # the same job again with the exchange by peer writes: same frames, steps, barriers; every rank takes part
         h.close()
@@ -536,10 +619,12 @@ def main():
         for k in range(nslots):
             h.upload_frame(k, host_frames[k])
         e2, lat2 = timed(h, args.steps, args.warmup)
+        own2 = own[0]
         dump_joints(h, "pyramid_p2p")
+        tim2 = profile(lambda n: run(h, n), h, nprof)
         pyramid_p2p = {"value": round(args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
                        "exchange": "peer writes over xGMI (exchange_kernel)",
-                       "latency_ms": {"p50": round(float(np.percentile(lat2, 50)), 4), "p95": round(float(np.percentile(lat2, 95)), 4)}}
+                       "latency_ms": latency_summary(lat2, args.steps), "per_rank": rank_report(lat2, own2, tim2)}
     out = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -564,10 +649,13 @@ def main():
                        "parallelism": ("pyramid: 1 scale per GPU + one %s exchange of the maps per frame"
                                        % ("RCCL all-gather" if args.exchange == "rccl" else "peer-write (xGMI)"))
                                       if args.pyramid else "stream replicas"},
-            "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p95": round(float(np.percentile(lat, 95)), 4),
-                           "max": round(float(lat.max()), 4)},
+            "latency_ms": latency_summary(lat, args.steps),
             # evidence of what ran: ranks counted by an all-reduce on the process-group backend, and every rank's device
             "rccl_ranks": ranks_seen if backend == "nccl" else None, "backend": backend, "backend_ranks": ranks_seen,
+            # (round 6) what explains an N > 1 curve, rank by rank: each rank's OWN rate over its K frames (`value` is N K / the slowest
+            # rank's time), its latency distribution, its conv stack on the device clock, the shader clock its GPU held under load
+            # (eight GPUs share a node's power), where its host thread sat; and the N = 1 loop of the same job
+            "per_rank": per_rank, "n1_same_job": n1_same_job, "build": _native.build_info()["text"],
             "ranks": placement, "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("VNECT_BENCH_SPAWNED") else
                                                ("launcher (RANK / WORLD_SIZE in the environment)" if args.gpus > 1 else "single process"),
             "exchange": (("rccl: ncclAllGather of 710 976 B per rank" if args.exchange == "rccl" else "p2p: peer writes over xGMI")
@@ -615,7 +703,7 @@ def main():
                        "dtype": "bf16", "steps": args.steps, "warmup": args.warmup,
                        "config": "BASELINE.json configs[2]: same frames and scales, bf16 operands / activations, fp32 accumulate, fp32 "
                                  "final maps, f64 post-processing; tolerance-gated against fp32 in tests/test_gpu_bf16.py",
-                       "latency_ms": {"p50": round(float(np.percentile(latb, 50)), 4), "p95": round(float(np.percentile(latb, 95)), 4)},
+                       "latency_ms": latency_summary(latb, args.steps),
                        "pipelined_frames_per_s_per_gpu": round(bf16_pipelined, 2),
                        "roofline": roofline(timb, nprof, "bf16")}
 
@@ -645,7 +733,7 @@ def main():
                              "steps": args.steps, "warmup": args.warmup,
                              "config": "BASELINE.json configs[1] workload; precision = VNECT_FP32_SPLIT; parity gates of the fp32 path "
                                        "(tests/test_gpu_split.py::test_split_product_path_meets_the_fp32_gates: error vs the oracle equal to the fp32 instruction's)",
-                             "latency_ms": {"p50": round(float(np.percentile(lats, 50)), 4), "p95": round(float(np.percentile(lats, 95)), 4)},
+                             "latency_ms": latency_summary(lats, args.steps),
                              "pipelined_frames_per_s_per_gpu": round(split_pipelined, 2),
                              "roofline": roofline(tims, nprof, "fp32_split")}
 

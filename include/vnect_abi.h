@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VNECT_ABI_VERSION 5
+#define VNECT_ABI_VERSION 6
 #define VNECT_MAX_SCALES 8
 #define VNECT_MAX_STREAMS 4 /* independent video streams one handle can serve (vnect_submit_stream) */
 #define VNECT_BOX 368      /* src/estimator.py:19 box_size   */
@@ -93,6 +93,14 @@ void vnect_destroy(vnect_handle* h);
 /* Message of the last failure on h (h == NULL: last vnect_create failure). Never NULL. */
 const char* vnect_last_error(vnect_handle* h);
 int vnect_abi_version(void);
+
+/* ABI v6.  How THIS binary was built, as one line of `key=value` text (static storage, never NULL): `abi`, `compiler`, `flags`, `variant`
+ * (the Makefile's VARIANT, empty for the product), `test_hooks` (1 only in the test build that can inject warm-start failures), every
+ * compile-time probe switch of the kernel sources with its value (X3_DBG, WT_DBG, CH_DBG, F32_NOSTORE, BF16_NOSTORE, VNECT_AB, NS_6432,
+ * NS_32128, POST_DBG, ARG_SLABS, ARG_ROWSPLIT -- most of them give wrong results on purpose) and `probes_off` = 1 iff all of them are
+ * at their product values.  A deployment check (and tests/test_abi_cpu.py) reads `probes_off=1 test_hooks=0`.  Replaces nothing in the
+ * reference: its counterpart is knowing which TensorFlow build `import tensorflow` loaded (src/estimator.py:9).                        */
+const char* vnect_build_info(void);
 
 /* Replaces VNect.load_weights / assign_weights_from_dict (src/vnect_model.py:219-236).
  * name is a key of the reference's pickle schema (src/caffe2pkl.py:51-80), e.g.
@@ -185,6 +193,12 @@ typedef struct vnect_timings {
                                   start of the kernel behind it (own duration + median boundary where another kind of
                                   kernel follows).  rocprofv3's per-kernel durations abut the same way (dispatch ->
                                   completion), so this is the figure its --stats average agrees with.  Summed.          */
+    /* ABI v6 (a caller compiled against v5 passes the shorter struct_size and gets the fields above): the shader clock the chip HELD
+     * while the conv launches of the profiled frames ran -- workgroup 0 of every conv launch stamps the shader-cycle counter
+     * (s_memtime) and the 100 MHz clock (s_memrealtime) at its start and its end; clock [MHz] = 100 * shader_cycles / shader_ticks.
+     * What an N > 1 run needs to tell a clock-limited rank (eight GPUs sharing a node's power) from a host-limited one.              */
+    double shader_cycles;      /* sum over conv launches and profiled frames of workgroup 0's span in shader cycles                */
+    double shader_ticks;       /* the same spans in 100 MHz ticks                                                                  */
 } vnect_timings;
 /* Profiling replays a twin of the frame graph in which every conv kernel stamps its start and end with the
  * 100 MHz device clock (s_memrealtime); off by default, no cost when off. */
@@ -205,7 +219,8 @@ int vnect_get_layer_info(vnect_handle* h, int idx, vnect_layer_info* out);
 /* Raw 100 MHz device-clock stamps of layer idx in the last profiled frame (tuning aid): [0] earliest workgroup start,
  * [1..8] latest workgroup ends, [9..13] workgroup 0: start, operands requested, first chunk in LDS, K loop done,
  * stores done; [15] start of the last-dispatched workgroups; [16..18] shader-clock cycles producer wave 0 of workgroup
- * 0 spent waiting for landings / at the barrier / issuing; [19] cycles consumer wave 0 waited at the barrier. */
+ * 0 spent waiting for landings / at the barrier / issuing; [19] cycles consumer wave 0 waited at the barrier.  (24 values:
+ * the shader-clock stamps of ABI v6 are reported through vnect_timings, not here.) */
 int vnect_get_layer_stamps(vnect_handle* h, int idx, uint64_t* out24);
 
 /* Pyramid sharding over RCCL (one scale per rank; BASELINE.json configs[3]).  A handle created with

@@ -41,6 +41,42 @@ def test_struct_sizes_match_header_layout():
     assert _native.Config.preprocess_only.offset == 120 and _native.Config.exchange.offset == 124
     assert _native.Config.scales.offset == 16
     assert C.sizeof(_native.LayerInfo) == 64 + 7 * 4 + 4 + 16
+    # vnect_timings: ABI v6 appended the two shader-clock doubles behind the v5 layout (56 bytes), which the library still accepts
+    assert C.sizeof(_native.Timings) == 72 and _native.Timings.shader_cycles.offset == 56 and _native.Timings.conv_slot_ms.offset == 48
+    hdr = open(os.path.join(ROOT, "include", "vnect_abi.h")).read()
+    body = hdr[hdr.index("typedef struct vnect_timings {"):hdr.index("} vnect_timings;")]
+    fields = re.findall(r"^\s*(?:int32_t|double)\s+(\w+);", body, re.M)
+    assert fields == [k for k, _ in _native.Timings._fields_], fields
+
+
+def test_shipped_library_was_built_with_every_probe_off():
+    """The kernel sources carry timing probes behind -D switches, most of which give WRONG results on purpose (X3_DBG, WT_DBG, CH_DBG,
+    POST_DBG, F32_NOSTORE, BF16_NOSTORE, VNECT_AB), tunables (NS_*, ARG_*) and the host runtime a test-only fault hook
+    (VNECT_TEST_HOOKS).  vnect_build_info() reports what THIS binary was compiled with: the library the product loads -- the file
+    bench.py and every GPU test run -- must have all of them at their product values, whatever EXTRA= a tuning session left behind."""
+    info = _native.build_info()
+    assert info["abi"] == str(_native.ABI_VERSION)
+    assert info["probes_off"] == "1" and info["test_hooks"] == "0" and info["variant"] == "", info["text"]
+    want = {"X3_DBG": "0", "WT_DBG": "0", "CH_DBG": "0", "F32_NOSTORE": "0", "BF16_NOSTORE": "0", "VNECT_AB": "0", "NS_6432": "5",
+            "NS_32128": "5", "POST_DBG": "0", "ARG_SLABS": "8", "ARG_ROWSPLIT": "1"}
+    got = dict(kv.split("=") for kv in (info["conv"] + " " + info["post"]).split())
+    assert got == want, got
+    assert "-O3" in info["flags"] and "gfx950" in info["flags"] and "-D" not in info["flags"], info["flags"]
+    assert "clang" in info["compiler"].lower()
+    # every probe macro the sources know is one the report covers (a new probe must be added to the report, or this fails)
+    csrc = os.path.join(ROOT, "vnect_amd", "csrc")
+    known = set()
+    for f in ("conv.hip", "post.hip", "stem.hip"):
+        known |= set(re.findall(r"^#ifndef ((?:[A-Z0-9]+_DBG|[A-Z0-9]+_NOSTORE|VNECT_AB|NS_[0-9]+|ARG_[A-Z]+))$", open(os.path.join(csrc, f)).read(), re.M))
+    assert known == set(want), known ^ set(want)
+    # the test twin says what it is, and is a different file from the one the product loads
+    if os.path.exists(_native.TESTHOOKS_LIB):
+        import ctypes as C
+        T = C.CDLL(_native.TESTHOOKS_LIB)
+        T.vnect_build_info.restype = C.c_char_p
+        t = T.vnect_build_info().decode()
+        assert "test_hooks=1" in t and "variant=_testhooks" in t and "probes_off=1" in t
+    assert os.path.basename(_native.LIB_PATH) == "libvnect_hip.so" or os.environ.get("VNECT_LIB")
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")

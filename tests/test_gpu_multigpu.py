@@ -103,8 +103,35 @@ def _host_stacked_pyramid(weights):
     return np.stack(j2s), np.stack(j3s)
 
 
+def _check_self_explaining(d, n, same_device, replicas):
+    """Round 6: an N > 1 line must explain itself with nobody there to debug it -- each rank's own rate / latency / conv-stack time /
+    shader clock under load, where its host thread sat, and the N = 1 loop of the same job."""
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(n)) and len(d["ranks"]) == n
+    for r in pr:
+        assert r["frames_per_s"] > 0 and r["own_elapsed_s"] > 0 and r["latency_ms"]["p50"] > 0 and r["latency_ms"]["p95"] >= r["latency_ms"]["p50"]
+        assert abs(r["frames_per_s"] - d["steps"] / r["own_elapsed_s"]) <= 1e-2 * r["frames_per_s"]
+        assert 0 < r["conv_stack_ms"] <= r["frame_ms_hip_events"] * 1.05
+        assert 800 < r["shader_clock_mhz"] < 2600, r        # MI355X: up to 2.4 GHz; the conv stack holds ~2.1 under load
+        assert "bound" in r["host_binding"] and ("affinity" in r["host_binding"] or "reason" in r["host_binding"])
+    # `value` is N K / the SLOWEST rank's time (barrier to barrier): no rank's own rate is below value / N by more than the barrier's cost
+    if replicas:
+        assert min(r["frames_per_s"] for r in pr) >= 0.97 * d["value"] / n, (d["value"], [r["frames_per_s"] for r in pr])
+    for r in d["ranks"]:
+        hb = r["host_binding"]
+        assert isinstance(hb["bound"], bool) and (hb["bound"] is False or hb["n_cpus"] >= 1)
+        if hb.get("bdf") is not None and "bdf_is_the_hip_device" in hb:
+            assert hb["bdf_is_the_hip_device"] is True, hb   # the sysfs chain and HIP name the same device
+    n1 = d["n1_same_job"]
+    assert n1 and n1["rank"] == 0 and n1["value"] > 0 and n1["steps"] == d["steps"] and n1["latency_ms"]["p50"] > 0
+    # (whether a rank COULD bind depends on what sysfs the container shows: a rank that could not says why -- never a parity failure)
+    assert all(r["host_binding"]["bound"] or r["host_binding"].get("reason") for r in pr), [r["host_binding"] for r in pr]
+    assert "probes_off=1" in d["build"] and "test_hooks=0" in d["build"]
+
+
 def _check_replicas(weights, d, prefix, n, same_device):
     assert d["n_gpus"] == n and d["backend_ranks"] == n and d["scaling"] == "weak" and len(d["ranks"]) == n
+    _check_self_explaining(d, n, same_device, replicas=True)
     if not same_device:
         assert d["rccl_ranks"] == n and d["backend"] == "nccl"
         assert len({r["pci_bus_id"] for r in d["ranks"]}) == n and sorted(r["device"] for r in d["ranks"]) == list(range(n)), d["ranks"]
@@ -137,6 +164,8 @@ def test_needs_3_gpus_pyramid_both_exchange_forms_bit_equal(weights, tmp_path):
     assert d["rccl_ranks"] == 3 and d["backend"] == "nccl" and d["n_gpus"] == 3 and d["scaling"] == "strong"
     assert len({r["pci_bus_id"] for r in d["ranks"]}) == 3 and sorted(r["device"] for r in d["ranks"]) == [0, 1, 2], d["ranks"]
     assert d["exchange"].startswith("rccl") and d["pyramid_p2p"] and d["pyramid_p2p"]["value"] > 0
+    _check_self_explaining(d, 3, same_device=False, replicas=False)
+    assert [r["rank"] for r in d["pyramid_p2p"]["per_rank"]] == [0, 1, 2]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "multigpu_pyramid_both.json"), "w") as f:
         json.dump(d, f, indent=1)
@@ -236,6 +265,7 @@ def test_needs_2_gpus_stream_replicas_rccl(weights, tmp_path):
     _check_replicas(weights, two, prefix, 2, same_device=False)
     per_gpu = two["value"] / 2
     assert abs(per_gpu - one["value"]) <= 0.10 * one["value"], (per_gpu, one["value"])
+    assert abs(per_gpu - two["n1_same_job"]["value"]) <= 0.10 * two["n1_same_job"]["value"], (per_gpu, two["n1_same_job"])
 
 
 # ------------------------------------------------------------------------------------------ rehearsals: the same checks on ONE device
@@ -256,6 +286,7 @@ def test_rehearsal_one_device_pyramid_p2p_gloo(weights, tmp_path):
     d = _bench(["--gpus", "3", "--pyramid-both", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--dump-joints", prefix],
                _clean_env(VNECT_BENCH_BACKEND="gloo", VNECT_BENCH_DEVICE="0"))
     assert d["backend_ranks"] == 3 and d["exchange"].startswith("p2p") and "RCCL leg" in d["note"]
+    _check_self_explaining(d, 3, same_device=True, replicas=False)
     _check_pyramid(weights, prefix, ["pyramid_p2p"])
 
 

@@ -19,7 +19,14 @@ elapsed = 0.5 + 0.25 * g.rank          # rank 1 is the slow one
 m = g.max_over_ranks(elapsed)
 assert m == 0.75, m
 rate = aggregate_rate(g.world, 30, m)
-print(json.dumps({"rank": g.rank, "max": m, "rate": rate, "sum": int(f.sum())}), flush=True)
+# the host-side hand-off bench.py's same-job N = 1 reference uses: rank 0 works alone, rank 1 waits on the STORE (no collective enqueued)
+t0 = time.time()
+if g.rank == 0:
+    time.sleep(0.6)
+how = g.host_handoff("n1_done", release=g.rank == 0)
+waited = time.time() - t0
+g.barrier()
+print(json.dumps({"rank": g.rank, "max": m, "rate": rate, "sum": int(f.sum()), "how": how, "waited": waited}), flush=True)
 g.close()
 """
 
@@ -41,6 +48,8 @@ def test_two_rank_stream_replicas_gloo(tmp_path):
     assert {o["rank"] for o in outs} == {0, 1}
     assert all(o["max"] == 0.75 and abs(o["rate"] - 2 * 30 / 0.75) < 1e-9 for o in outs)
     assert outs[0]["sum"] != outs[1]["sum"]   # the two streams are different videos
+    by = {o["rank"]: o for o in outs}
+    assert by[0]["how"] == by[1]["how"] == "store" and by[1]["waited"] >= 0.5   # rank 1 sat in the store wait while rank 0 "ran alone"
 
 
 def test_world_one_needs_no_process_group():
@@ -49,7 +58,7 @@ def test_world_one_needs_no_process_group():
     saved = {k: os.environ.pop(k, None) for k in env_keys}
     try:
         g = Group("gloo")
-        assert g.world == 1 and g.max_over_ranks(1.5) == 1.5
+        assert g.world == 1 and g.max_over_ranks(1.5) == 1.5 and g.host_handoff("x", release=True) == "none"
         g.barrier()
         g.close()
         assert stream_seed(3, 7) == 1234 + 3000 + 7
@@ -242,3 +251,86 @@ print("ok")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------- host placement of a rank (round 6)
+def _fake_sysfs(root, gpus, cpu_nodes=2):
+    """A sysfs tree with `cpu_nodes` CPU nodes in front of the GPU nodes: gpus = [(domain, bus, dev, fn, local_cpulist, numa_node), ...]."""
+    base = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    n = 0
+    for _ in range(cpu_nodes):
+        os.makedirs(os.path.join(base, str(n)))
+        open(os.path.join(base, str(n), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+        n += 1
+    for dom, bus, dev, fn, cpus, numa in gpus:
+        os.makedirs(os.path.join(base, str(n)))
+        open(os.path.join(base, str(n), "properties"), "w").write(
+            "cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain %d\n" % ((bus << 8) | (dev << 3) | fn, dom))
+        d = os.path.join(root, "bus", "pci", "devices", "%04x:%02x:%02x.%x" % (dom, bus, dev, fn))
+        os.makedirs(d)
+        if cpus is not None:
+            open(os.path.join(d, "local_cpulist"), "w").write(cpus + "\n")
+            open(os.path.join(d, "numa_node"), "w").write("%d\n" % numa)
+        n += 1
+
+
+def test_rank_binding_parser_on_a_fake_sysfs(tmp_path):
+    """vnect_amd.parallel: where a rank's host thread goes, decided from sysfs alone (no GPU call): cpulist parsing, the KFD nodes ->
+    PCI address -> local_cpulist chain, *_VISIBLE_DEVICES reordering, the intersection with the process's own affinity."""
+    from vnect_amd import parallel as P
+    assert P.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and P.parse_cpulist("") == [] and P.parse_cpulist(" 5 ") == [5]
+    assert P.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == "0-3,8,10-11" and P.format_cpulist([]) == ""
+    for text in ("0-63,128-191", "7", "0,2,4,6"):
+        assert P.format_cpulist(P.parse_cpulist(text)) == text
+    root = str(tmp_path / "sys")
+    gpus = [(0, 0x05, 0, 0, "0-63,128-191", 0), (0, 0x15, 0, 0, "0-63,128-191", 0), (0, 0x85, 0, 0, "64-127,192-255", 1),
+            (1, 0x95, 1, 2, "64-127,192-255", 1), (0, 0xa5, 0, 0, None, -1)]
+    _fake_sysfs(root, gpus)
+    assert P.gpu_bdfs(root) == ["0000:05:00.0", "0000:15:00.0", "0000:85:00.0", "0001:95:01.2", "0000:a5:00.0"]   # CPU nodes skipped
+    b = P.rank_binding(2, sysfs=root, env={})
+    assert b["bdf"] == "0000:85:00.0" and b["numa_node"] == 1 and b["cpus"] == list(range(64, 128)) + list(range(192, 256))
+    # the cgroup / taskset limit is respected: only local cores the process may already use
+    b = P.rank_binding(3, sysfs=root, env={}, allowed=range(100, 200))
+    assert b["bdf"] == "0001:95:01.2" and b["cpus"] == list(range(100, 128)) + list(range(192, 200))
+    b = P.rank_binding(0, sysfs=root, env={}, allowed=[70, 71])
+    assert b["cpus"] is None and "affinity" in b["reason"] and b["local_cpulist"] == "0-63,128-191"
+    # *_VISIBLE_DEVICES: ROCr filters first, HIP indexes into what is left
+    assert P.visible_order({}) is None and P.visible_order({"HIP_VISIBLE_DEVICES": "3,1"}) == [3, 1]
+    assert P.visible_order({"ROCR_VISIBLE_DEVICES": "4,2,0", "HIP_VISIBLE_DEVICES": "1,0"}) == [2, 4]
+    assert P.visible_order({"HIP_VISIBLE_DEVICES": "GPU-abcdef"}) == "unknown"
+    assert P.rank_binding(0, sysfs=root, env={"HIP_VISIBLE_DEVICES": "2,3"})["bdf"] == "0000:85:00.0"
+    assert P.rank_binding(0, sysfs=root, env={"HIP_VISIBLE_DEVICES": "GPU-abcdef"})["cpus"] is None
+    # failures say why and never raise: no local_cpulist, a device sysfs does not show, a machine without KFD
+    assert "local_cpulist" in P.rank_binding(4, sysfs=root, env={})["reason"]
+    assert "not among" in P.rank_binding(7, sysfs=root, env={})["reason"]
+    assert "no KFD" in P.rank_binding(0, sysfs=str(tmp_path / "nothing"), env={})["reason"]
+
+
+def test_bind_rank_applies_and_reports(tmp_path):
+    """bind_rank on a fake sysfs whose device is local to a SUBSET of this process's cores: the affinity mask is narrowed (in a child
+    process), the report says so; --no-bind and a machine without GPUs leave it alone."""
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 2:
+        import pytest
+        pytest.skip("one core")
+    from vnect_amd import parallel as P
+    root = str(tmp_path / "sys")
+    half = avail[: len(avail) // 2]
+    _fake_sysfs(root, [(0, 0x05, 0, 0, P.format_cpulist(half), 0)])
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+from vnect_amd import parallel as P
+rep = P.bind_rank(0, enable=True, sysfs=%r)
+print(json.dumps({"rep": rep, "now": sorted(os.sched_getaffinity(0))}))
+""" % (ROOT, root)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["now"] == half and out["rep"]["bound"] is True and out["rep"]["n_cpus"] == len(half) and out["rep"]["narrowed_from"] == len(avail)
+    assert out["rep"]["bdf"] == "0000:05:00.0" and out["rep"]["affinity"] == P.format_cpulist(half)
+    rep = P.bind_rank(0, enable=False, sysfs=root)
+    assert rep["bound"] is False and rep["reason"] == "--no-bind" and sorted(os.sched_getaffinity(0)) == avail
+    rep = P.bind_rank(0, enable=True, sysfs=str(tmp_path / "nothing"))
+    assert rep["bound"] is False and "no KFD" in rep["reason"] and sorted(os.sched_getaffinity(0)) == avail

@@ -15,7 +15,7 @@ _lib = None
 
 MAX_SCALES = 8
 OK, E_ARG, E_STATE, E_HIP, E_NODEVICE, E_TIMESTAMP, E_COMM, E_TIMEORDER, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_STREAMS = 4
 XCHG_RCCL, XCHG_P2P = 0, 1
 FP32, BF16, FP32_SPLIT = 0, 1, 2
@@ -38,7 +38,8 @@ class Config(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("frames", C.c_int32), ("total_ms", C.c_double), ("net_ms", C.c_double),
-                ("conv_ms", C.c_double), ("conv_launches", C.c_int32), ("conv_flops", C.c_double), ("conv_slot_ms", C.c_double)]
+                ("conv_ms", C.c_double), ("conv_launches", C.c_int32), ("conv_flops", C.c_double), ("conv_slot_ms", C.c_double),
+                ("shader_cycles", C.c_double), ("shader_ticks", C.c_double)]   # ABI v6: clock [MHz] = 100 * cycles / ticks
 
 
 class LayerInfo(C.Structure):
@@ -52,6 +53,7 @@ _f32p, _f64p, _u8p, _i32p = (C.POINTER(t) for t in (C.c_float, C.c_double, C.c_u
 _H = C.c_void_p
 SYMBOLS = {
     "vnect_abi_version": (C.c_int, []),
+    "vnect_build_info": (C.c_char_p, []),
     "vnect_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "vnect_destroy": (None, [_H]),
     "vnect_last_error": (C.c_char_p, [_H]),
@@ -86,12 +88,31 @@ SYMBOLS = {
 }
 
 
+TESTHOOKS_LIB = os.path.join(_HERE, "lib", "libvnect_hip_testhooks.so")   # the host runtime with -DVNECT_TEST_HOOKS=1 (tests only)
+
+
 def build(force=False):
-    """hipcc --offload-arch=gfx950 build of the library (works without a GPU)."""
+    """hipcc --offload-arch=gfx950 build of the library (works without a GPU), and of its test twin: the same kernel objects under a
+    host runtime compiled with the warm start's failure injection (`make testhooks`; only tests/test_gpu_surface.py loads it)."""
     src = os.path.join(_HERE, "csrc")
     cmd = ["make", "-C", src] + (["-B"] if force else [])
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src, "testhooks"], stdout=subprocess.DEVNULL)
     return LIB_PATH
+
+
+def build_info():
+    """vnect_build_info() as a dict: {"abi": "6", "compiler": ..., "flags": ..., "variant": "", "test_hooks": "0", "probes_off": "1",
+    "conv": "X3_DBG=0 ...", "post": "..."}."""
+    text = lib().vnect_build_info().decode()
+    out = {"text": text}
+    for part in text.split("; "):
+        if ": " in part and "=" not in part.split(": ", 1)[0]:
+            k, v = part.split(": ", 1)
+        else:
+            k, v = part.split("=", 1)
+        out[k.strip()] = v.strip()
+    return out
 
 
 def lib():
@@ -321,7 +342,10 @@ class Handle:
         t = Timings()
         t.struct_size = C.sizeof(Timings)
         self._ck(lib().vnect_get_timings(self._h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in Timings._fields_ if k != "struct_size"}
+        d = {k: getattr(t, k) for k, _ in Timings._fields_ if k != "struct_size"}
+        # the shader clock the chip held while the conv launches of the profiled frames ran (s_memtime / s_memrealtime of workgroup 0)
+        d["shader_clock_mhz"] = 100.0 * d["shader_cycles"] / d["shader_ticks"] if d["shader_ticks"] > 0 else None
+        return d
 
     def reset_timings(self):
         self._ck(lib().vnect_reset_timings(self._h))

@@ -14,6 +14,12 @@
 #ifndef X3_DBG
 #define X3_DBG 0  // tuning builds only (make VARIANT=_b EXTRA=-DX3_DBG=n): timing probes of the split-product loop, wrong results
 #endif
+#ifndef VNECT_AB
+#define VNECT_AB 0  // tuning builds only: store forms of the epilogue (1 plain, 2 streaming, 3 write-through + streaming)
+#endif
+#ifndef BF16_NOSTORE
+#define BF16_NOSTORE 0  // tuning builds only (wrong results): no bf16 epilogue stores
+#endif
 
 #include <cstdlib>
 #include <type_traits>
@@ -666,7 +672,10 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
     const int kg = wave / WMN, wr = wave % WMN, wm = wr / WNW, wn = (wr % WNW) * NACC;  // consumers: K group, tile row block / first column block
     // start stamp: workgroup 0 (first dispatched; a grid starts first -> last within ~0.5 us).  Plain store: nothing in the
     // twin may queue behind an atomic.
-    if (P1 && threadIdx.x == 0 && blockIdx.x == 0) prof[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    if (P1 && threadIdx.x == 0 && blockIdx.x == 0) {
+        prof[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        prof[24] = (unsigned long long)__builtin_amdgcn_s_memtime();  // shader cycles: with [25], [26] the clock held during this launch
+    }
     const bool pstamp = P2 && threadIdx.x == 0 && blockIdx.x == 0;
     if (pstamp) prof[9] = __builtin_amdgcn_s_memrealtime();
     if (P2 && threadIdx.x == 0 && blockIdx.x + 8 >= gridDim.x) atomicMax(prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -1589,9 +1598,19 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         // its "stores drained" stamp) puts a store round trip in front of the stamp's own store in every workgroup
         if constexpr (P2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (pstamp) prof[13] = __builtin_amdgcn_s_memrealtime();
-        // (a grid above PROF_WGS -- the one-item launches of more than 512 tiles, round 5 -- shares slots: workgroup id and id + 512 finish a
-        // tile apart, so the later store is the later stamp, which is the one the host's maximum wants)
-        a.prof_end[blockIdx.x & (PROF_WGS - 1)] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) {  // workgroup 0's own span in both clocks (its end, not the launch's: one workgroup, one counter)
+            prof[25] = (unsigned long long)__builtin_amdgcn_s_memtime();
+            prof[26] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        }
+        // A grid above PROF_WGS (the one-item launches of more than 512 tiles, round 5) shares slots: workgroup id and id + 512 write the
+        // same one from different CUs, and plain stores of different CUs are not ordered (advisor, round 5: the host's maximum could be
+        // under-reported).  Those grids take the agent-scope atomic maximum -- the slots are zeroed per frame -- and grids that fit keep
+        // the plain store (an atomic in every workgroup of every launch put ~1.4 us behind each: round 2).
+        if (gridDim.x > PROF_WGS)
+            __hip_atomic_fetch_max(&a.prof_end[blockIdx.x & (PROF_WGS - 1)], (unsigned long long)__builtin_amdgcn_s_memrealtime(),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1663,6 +1682,7 @@ template <int BM, int BN, int KG, int NS>
 constexpr size_t x3_stream_lds() { return (size_t)NS * (BM * 32 + BN * 48) * KG * 4 + (KG > 1 ? (size_t)(KG - 1) * (4 / KG) * 4096 + 64 : 0); }
 constexpr int X3_NS = 4;  // 64x64: 4 stages of 20 KiB (the same 80 KB as 5 x 16 KiB: two workgroups per CU)
 // ring depths of the shapes that run ONE workgroup per CU
+static int g_cus = 256;  // compute units of the device the handles run on (conv_setup); MI355X: 256
 #ifndef NS_6432
 #define NS_6432 5
 #endif
@@ -1686,7 +1706,8 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     // two workgroups per CU at most (one for the K-group shapes: their ring fills the LDS): more tiles than that are
     // walked by the same workgroups (VNECT_MAXWG: tuning)
     static const int maxwg_env = getenv("VNECT_MAXWG") ? atoi(getenv("VNECT_MAXWG")) : 0;
-    const int maxwg = maxwg_env > 0 ? maxwg_env : (KG == 1 && BN <= 64 ? 512 : 256);
+    const int cus = g_cus;  // compute units of the device (conv_setup; 256 on MI355X)
+    const int maxwg = maxwg_env > 0 ? maxwg_env : (KG == 1 && BN <= 64 ? 2 * cus : cus);
     // One workgroup per item also ABOVE two per CU (round 5): the hardware starts the later workgroups as the earlier ones retire, each with the
     // lean one-item kernel's cold start (~1 us) instead of the streaming kernel's (~2 us) in front of every workgroup's few tiles.  Which launches
     // gain is a measurement (tools/ab_multi.sh, two calls, profiles/r05_ab_big_grids.txt), three launches of a 3-scale frame are concerned:
@@ -1694,7 +1715,7 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
     //   bf16: both pairs as one-item launches +1.0 % (res3a's alone -0.5 %, res5a's alone +0.3 %): every launch up to 1 024 tiles.
     static const bool no_one = getenv("VNECT_NO_ONE") != nullptr, no_big = getenv("VNECT_NO_BIG_GRID") != nullptr;  // A/B runs
     const bool plain64 = KG == 1 && BN <= 64 && maxwg_env <= 0 && !no_big && !a.x3 && !a.pixmode;
-    const bool big_grid = plain64 && (a.bf16 ? a.items <= 1024 : (a.ntaps * a.cpt <= 8 && a.items <= 2048));
+    const bool big_grid = plain64 && (a.bf16 ? a.items <= 4 * cus : (a.ntaps * a.cpt <= 8 && a.items <= 8 * cus));
     const bool one = a.ksplit == 1 && !no_one && (a.items <= maxwg || big_grid);
     dim3 grid(one ? a.items : (a.items < maxwg ? a.items : maxwg));
     const size_t lds = stream_lds<BM, BN, KG, NS>();
@@ -1735,7 +1756,9 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
                 return hipErrorInvalidValue;
             // the 64-wide chain: bf16, behind a tail with shortcut + ReLU and bf16 output only
             if (a.chain_n != 0 && (!a.bf16 || a.chain_n != 64 || !a.chain_w || !a.chain_bias || !a.chain_out || a.chain_ld < 64 || !a.resid ||
-                                   a.relu_cols < 256 || a.out_f32 || a.Nvalid != 256))
+                                   a.relu_cols < 256 || a.out_f32 || a.Nvalid != 256 ||
+                                   (a.ldc & 7) != 0))  // the chain stores the block output from the LDS tile, which tail_gemm fills only in its
+                                                       // staged form (tail_staged: whole 16-byte units per row, ldc % 8 == 0; advisor, round 5)
                 return hipErrorInvalidValue;
 #define LAUNCH_TAIL(BF, PR) hipLaunchKernelGGL((conv_stream_kernel<64, 64, 1, NS, BF, PR, 1>), grid, dim3(512), lds, st, a)
             if (a.bf16 && a.chain_n) {
@@ -1939,9 +1962,17 @@ static hipError_t setup_stream_rest()
 
 // Ring depths: 5 x 16 KiB leaves room for two 64x64 workgroups per CU (measured faster than one deeper ring on every
 // layer); the K-group shapes run one workgroup per CU.
+int conv_cu_count() { return g_cus; }
+
 hipError_t conv_setup()
 {
     hipError_t e;
+    {   // the launch plan's "rounds over the chip" are counted in compute units of the CURRENT device (advisor, round 5: no literal 256)
+        int dev = 0, n = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if (n >= 8) g_cus = n;
+    }
     if ((e = setup_stream<64, 64, 1, 5>()) != hipSuccess) return e;
     if ((e = setup_stream<64, 32, 2, NS_6432>()) != hipSuccess) return e;
     if ((e = setup_stream<32, 32, 4, 4>()) != hipSuccess) return e;
@@ -2064,6 +2095,20 @@ __global__ void bone_kernel(T* feat, long long npix, int ld)
     }
     f[191 + j] = (T)v;
 }
+// What this translation unit was compiled with (vnect_build_info): every timing probe must be off in the shipped library -- most of
+// them give WRONG results on purpose -- and the ring depths at their defaults.  `NS_*` are defined further up, next to their launchers.
+#define VNECT_STR2(x) #x
+#define VNECT_STR(x) VNECT_STR2(x)
+const char* conv_build_probes()
+{
+    return "X3_DBG=" VNECT_STR(X3_DBG) " WT_DBG=" VNECT_STR(WT_DBG) " CH_DBG=" VNECT_STR(CH_DBG) " F32_NOSTORE=" VNECT_STR(F32_NOSTORE)
+           " BF16_NOSTORE=" VNECT_STR(BF16_NOSTORE) " VNECT_AB=" VNECT_STR(VNECT_AB) " NS_6432=" VNECT_STR(NS_6432) " NS_32128=" VNECT_STR(NS_32128);
+}
+bool conv_probes_off()
+{
+    return X3_DBG == 0 && WT_DBG == 0 && CH_DBG == 0 && F32_NOSTORE == 0 && BF16_NOSTORE == 0 && VNECT_AB == 0 && NS_6432 == 5 && NS_32128 == 5;
+}
+
 hipError_t launch_bone(void* feat, long long npix, int ld, int bf16, hipStream_t st)
 {
     long long total = npix * (ld - 191);

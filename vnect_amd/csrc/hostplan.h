@@ -364,31 +364,34 @@ struct TileChoice {
     int BM = 64, BN = 64, KG = 1, ks = 1;
 };
 inline bool tile_shape_ok(int BM, int BN, int KG) { return (BM == 64 && BN == 64 && KG == 1) || (BM == 64 && BN == 32 && KG == 2) || (BM == 32 && BN == 32 && KG == 4) || (BM == 32 && BN == 128 && KG == 1); }
+// `cus` = compute units of the device (hipDeviceProp: multiProcessorCount; advisor, round 5): the tile-count thresholds below were
+// measured on the 256-CU MI355X and scale with the chip (a partitioned device, another SKU); at 256 they are the measured literals.
 inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int nphase, bool bf16, const std::string& name, const char* force,
-                              const char* plan, bool allow_deconv96 = false)
+                              const char* plan, bool allow_deconv96 = false, int cus = 256)
 {
     TileChoice c;
+    const long long half = cus / 2, full = cus, t200 = (long long)cus * 200 / 256, t72 = (long long)cus * 72 / 256, t64 = cus / 4;
     const int nch = ntaps * cpt;
     const int kel = K;  // K-elements (a chunk is 32 of them in fp32, 64 in bf16)
     const long long mt = (M + 63) / 64, nreal = Nreal;
     const long long tiles = mt * (round_up((int)nreal, 64) / 64) * nphase;
     // (tiles <= 72 && K >= 512: a single scale's 1x1 layers at 46x46 -- a pyramid rank's plan: `res3*_branch2a` 10.1 -> 7.0 us as 64x32x2)
-    if ((tiles <= 128 && kel >= 768) || (tiles <= 200 && kel >= 4096) || (tiles <= 72 && kel >= 512)) {
+    if ((tiles <= half && kel >= 768) || (tiles <= t200 && kel >= 4096) || (tiles <= t72 && kel >= 512)) {
         // Too few 64x64 tiles for 256 CUs and a long K: split K.  Inside the workgroup where that alone fills the chip
         // (one workgroup per CU, four K-parallel or M/N-parallel accumulators: no slabs, no reduce launch) ...
         const long long t64x32 = mt * (round_up((int)nreal, 32) / 32) * nphase;
         const long long t32x32 = ((M + 31) / 32) * (round_up((int)nreal, 32) / 32) * nphase;
-        if (t64x32 > 128 && t64x32 <= 256 && cpt % 2 == 0) c.BM = 64, c.BN = 32, c.KG = 2;
-        else if (t32x32 > 128 && t32x32 <= 256 && cpt % 4 == 0) c.BM = 32, c.BN = 32, c.KG = 4;
+        if (t64x32 > half && t64x32 <= full && cpt % 2 == 0) c.BM = 64, c.BN = 32, c.KG = 2;
+        else if (t32x32 > half && t32x32 <= full && cpt % 4 == 0) c.BM = 32, c.BN = 32, c.KG = 4;
         // ... else across workgroups: 5 partial slabs + splitk_reduce_kernel (bf16 loops are 2-3x shorter: there the extra
         // launch only pays for the smallest, deepest layers)
-        else if (!bf16 || (tiles <= 64 && kel >= 2048)) c.ks = std::min(5, nch);
+        else if (!bf16 || (tiles <= t64 && kel >= 2048)) c.ks = std::min(5, nch);
     }
     // The transposed conv in fp32 (round 4): 300 tiles of 64 x 64 on 256 CUs are TWO rounds for 44 of them; 64 x 96 tiles with two K groups
     // and three accumulators per wave (conv.hip: NACC) are 200 tiles, ONE round of 1.5 block-K-loops per SIMD.  Only this layer takes the
     // shape (no shortcut, one output tensor), only while its 64 x 64 plan needs a second round and the 96-wide one does not.
     const bool deconv96_ok = !bf16 && nphase == 4 && cpt % 2 == 0 && round_up((int)nreal, 96) == round_up((int)nreal, 64);
-    if (deconv96_ok && allow_deconv96 && tiles > 256 && mt * (round_up((int)nreal, 96) / 96) * nphase <= 256) c.BM = 64, c.BN = 96, c.KG = 2, c.ks = 1;
+    if (deconv96_ok && allow_deconv96 && tiles > full && mt * (round_up((int)nreal, 96) / 96) * nphase <= full) c.BM = 64, c.BN = 96, c.KG = 2, c.ks = 1;
     auto take = [&](const char* spec) {
         int fBM = 0, fBN = 0, fKG = 0, fks = 0;
         if (sscanf(spec, "%d,%d,%d,%d", &fBM, &fBN, &fKG, &fks) != 4 || fks < 1 || fks > 8 || cpt % std::max(fKG, 1) != 0) return;
@@ -415,18 +418,20 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
 // same columns as 64x32 tiles with two K groups take half a loop per round.  Returns how many leading channels of layer a to run as a
 // launch of their own (a multiple of 64 that choose_tile gives the 64x32x2 shape and ONE round), 0 if that does not beat the single
 // launch by more than it costs: a block K loop is K / 2 matrix instructions of 64 cycles at ~2.15 GHz, a dependent launch ~4 us
-// (floor + cold start).  fp32 only: a bf16 loop is a quarter of that and a launch is not.
-inline int pair_head_cols(int M, int cout_a, int cout_b, int K, bool bf16)
+// (floor + cold start).  fp32 only: a bf16 loop is a quarter of that and a launch is not.  `cus` = the device's compute
+// units (a round is one tile per CU); the clock and the launch cost are MI355X's (the decision is +0.6 % there: a wrong guess on another
+// part costs a fraction of a per cent, never correctness -- tools/switch_matrix.sh covers both plans).
+inline int pair_head_cols(int M, int cout_a, int cout_b, int K, bool bf16, int cus = 256)
 {
-    if (bf16 || K < 768 || K % 64) return 0;
+    if (bf16 || K < 768 || K % 64 || cus < 8) return 0;
     const long long mt = (M + 63) / 64, nt = (cout_a + cout_b) / 64;
     const double loop_us = K * 0.5 * 64 / 2150.0, launch_us = 4.0;
-    auto rounds = [](long long t) { return (double)((t + 255) / 256); };
+    auto rounds = [cus](long long t) { return (double)((t + cus - 1) / cus); };
     double best = rounds(mt * nt) * loop_us - 1.0;
     int head = 0;
     for (int c = 64; c < cout_a; c += 64) {
         const long long th = mt * (c / 32);
-        if (mt * (c / 64) > 128 || th <= 128 || th > 256) continue;  // (choose_tile's conditions for 64x32x2)
+        if (mt * (c / 64) > cus / 2 || th <= cus / 2 || th > cus) continue;  // (choose_tile's conditions for 64x32x2)
         const double t = rounds(mt * (nt - c / 64)) * loop_us + 0.5 * loop_us + launch_us;
         if (t < best) best = t, head = c;
     }

@@ -10,7 +10,9 @@ namespace vnect {
 constexpr int MAX_TAPS = 16;
 constexpr int ARG_SLABS_MAX = 32;  // upper bound of the arg-max workgroups per joint (post.hip: ARG_SLABS): what the partials' buffer is sized for
 constexpr int PROF_WGS = 512;   // end-stamp slots per launch (two workgroups per CU; a power of two: larger grids wrap around)
-constexpr int PROF_SLOTS = 24;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7
+constexpr int PROF_SLOTS = 28;  // u64 per layer in the profiling buffer: [0] min start, [1..8] max end per id&7, [9..23] tuning stamps
+                                // (vnect_get_layer_stamps), [24..26] workgroup 0: shader-clock counter (s_memtime) at its start and at its
+                                // end, 100 MHz stamp at its end -- the clock the chip held during the launch (round 6)
 
 // Implicit-GEMM convolution: out[m][n] = sum_k A[m][k] * Wp[n][k],
 //   m = (s*Ho + oy)*Wo + ox, k = (tap, ci), A[m][k] = in[s][oy*stride + dy[tap]][ox*stride + dx[tap]][ci]
@@ -110,6 +112,12 @@ hipError_t launch_conv(const ConvArgs& a, int BM, int BN, int KG, hipStream_t st
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
 hipError_t conv_setup();  // one-time function attributes (dynamic LDS size)
 bool conv_deconv96_available();  // after conv_setup: the 64x96x2 three-accumulator instantiations fit the register file
+int conv_cu_count();             // after conv_setup: compute units of the device (what a "round over the chip" is counted in)
+// compile-time probe switches of the kernel translation units, as text and as "all at their product values" (vnect_build_info)
+const char* conv_build_probes();
+bool conv_probes_off();
+const char* post_build_probes();
+bool post_probes_off();
 
 hipError_t launch_pad3to4(const float* in3, void* out4, long long npix, int bf16, hipStream_t st);
 hipError_t launch_strip4to3(const void* in4, float* out3, long long npix, int bf16, hipStream_t st);
@@ -131,7 +139,7 @@ struct FrameDyn {     // what does change every frame: passed to the two kernels
 hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* tabs, void* batch4, int S, int scale_base, int bf16, hipStream_t st);
 
 // vnect_infer: H rows of `row` bytes from device-mapped pinned host memory (`stride` bytes apart) into a resident frame slot, as a kernel
-hipError_t launch_frame_copy(const uint8_t* src_dev, uint8_t* dst, int H, int row, long long stride, hipStream_t st);
+hipError_t launch_frame_copy(const uint8_t* src_dev, uint8_t* dst, int H, int row, long long stride, const uint8_t* src_end, hipStream_t st);
 
 // ---- the stem as one launch (stem.hip): [gen_input_batch ->] conv1 + ReLU -> 3x3 / stride-2 max-pool on spatial tiles -------------
 struct StemArgs {

@@ -42,7 +42,7 @@ hipError_t launch_pyramid(const FrameParams* fp, FrameDyn dyn, const ScaleTabs* 
 // (src, stride bytes apart) to the resident frame slot (dst, rows packed).  hipMemcpyAsync of the same 406 KB costs ~21 us of a
 // synchronous frame on this runtime (the copy engine and its hand-over to the compute queue); a kernel in front of the stem costs the
 // PCIe transfer (~8 us) and one dependent boundary.  Three forms, chosen on the host: whole 16-byte units of one contiguous run, dwords
-// per row, bytes per row.
+// per row, and -- for rows that are not dword-aligned -- frame_copy_rows_kernel below.
 __global__ __launch_bounds__(256) void frame_copy_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int row, long long stride, int form)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -51,25 +51,70 @@ __global__ __launch_bounds__(256) void frame_copy_kernel(const uint8_t* __restri
         const long long n = (long long)H * row, n16 = n >> 4;
         if (i < n16) ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
         if (i < (n & 15)) dst[(n16 << 4) + i] = src[(n16 << 4) + i];
-    } else if (form == 1) {   // dword-aligned rows
+    } else {                  // dword-aligned rows
         const int rw = row >> 2;
         const long long y = i / rw;
         const int x = (int)(i - y * rw);
         if (y < H) ((unsigned*)(dst + y * row))[x] = ((const unsigned*)(src + y * stride))[x];
-    } else {
-        const long long y = i / row;
-        const int x = (int)(i - y * row);
-        if (y < H) dst[y * row + x] = src[y * stride + x];
     }
 }
-hipError_t launch_frame_copy(const uint8_t* src_dev, uint8_t* dst, int H, int row, long long stride, hipStream_t st)
+// Rows at ANY byte alignment (advisor, round 5): a crop the tracking loop cuts out of a pinned capture buffer starts at byte 3 * x0 of a
+// frame row and is 3 * w bytes wide (/root/reference/run_estimator_ps.py:88), so three crops in four are not dword-aligned -- and the
+// byte-per-thread form they used to take read the pinned buffer over PCIe one byte per lane.  Here every lane loads ONE aligned source
+// dword (a wave: 64 consecutive dwords = whole PCIe read requests), takes its neighbour's through a lane shuffle, and v_alignbyte
+// assembles the destination dword; a wave writes 63 destination dwords.  The destination rows are packed (row bytes apart), so a row
+// starts at byte (y * row) & 3 of the destination's dword grid: interior dwords are whole stores, the first / last dword of a row is
+// shared with its neighbours and written byte by byte.  grid = (ceil(dwords per row / 252), H), 256 threads.
+__global__ __launch_bounds__(256) void frame_copy_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int row, long long stride,
+                                                              const uint8_t* src_end)
+{
+    const int y = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uintptr_t s = (uintptr_t)src + (unsigned long long)y * (unsigned long long)stride;  // first source byte of the row
+    const uintptr_t d = (uintptr_t)dst + (unsigned long long)y * (unsigned long long)row;      // first destination byte
+    const uintptr_t d0 = d & ~(uintptr_t)3;                                                    // the destination's dword grid
+    const int ad = (int)(d - d0);                   // bytes of destination dword 0 in front of the row
+    const int ndw = (ad + row + 3) >> 2;            // destination dwords the row touches
+    const int k0 = ((int)blockIdx.x * 4 + wave) * 63;  // this wave's first destination dword (wave-uniform)
+    if (k0 >= ndw) return;
+    // destination dword k holds row bytes [4k - ad, 4k - ad + 4): its first source byte is s + 4k - ad
+    const uintptr_t sb = s + 4ull * (unsigned)k0 - (unsigned)ad;
+    const uintptr_t sa = sb & ~(uintptr_t)3;
+    const int sh = (int)(sb - sa);
+    const uintptr_t mine = sa + 4ull * (unsigned)lane;
+    // (an aligned dword may start up to 3 bytes in front of the row and end up to 3 bytes behind it: inside the pinned buffer, whose
+    // base and capacity are multiples of 4 -- `src_end` is its end; bytes outside the row are never stored)
+    unsigned lo = 0;
+    if (mine + 4 <= (uintptr_t)src_end && mine < s + (unsigned)row + 4) lo = *(const unsigned*)mine;
+    const unsigned hi = (unsigned)__shfl_down((int)lo, 1);
+    const unsigned v = sh == 0 ? lo : (sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1) : (sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2) : __builtin_amdgcn_alignbyte(hi, lo, 3)));
+    const int k = k0 + lane;
+    if (lane == 63 || k >= ndw) return;
+    const int b0 = 4 * k - ad;                      // row byte index of the dword's byte 0
+    if (b0 >= 0 && b0 + 4 <= row) {
+        ((unsigned*)d0)[k] = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (b0 + j >= 0 && b0 + j < row) ((uint8_t*)d0)[4 * k + j] = (uint8_t)(v >> (8 * j));
+    }
+}
+// `src_end`: end of the pinned buffer `src_dev` lies in (device address; only the any-alignment form reads it)
+hipError_t launch_frame_copy(const uint8_t* src_dev, uint8_t* dst, int H, int row, long long stride, const uint8_t* src_end, hipStream_t st)
 {
     const long long n = (long long)H * row;
-    int form = 2;
-    long long threads = n;
-    if (stride == row && (((uintptr_t)src_dev | (uintptr_t)dst) & 15) == 0) form = 0, threads = (n >> 4) > 16 ? (n >> 4) : 16;
-    else if (((row | stride) & 3) == 0 && (((uintptr_t)src_dev | (uintptr_t)dst) & 3) == 0) form = 1, threads = n >> 2;
-    hipLaunchKernelGGL(frame_copy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, src_dev, dst, H, row, stride, form);
+    if (stride == row && (((uintptr_t)src_dev | (uintptr_t)dst) & 15) == 0) {
+        const long long threads = (n >> 4) > 16 ? (n >> 4) : 16;
+        hipLaunchKernelGGL(frame_copy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, src_dev, dst, H, row, stride, 0);
+    } else if (((row | stride) & 3) == 0 && (((uintptr_t)src_dev | (uintptr_t)dst) & 3) == 0) {
+        hipLaunchKernelGGL(frame_copy_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, st, src_dev, dst, H, row, stride, 1);
+    } else {
+        const int ndw_max = (3 + row + 3) >> 2;
+        for (int y0 = 0; y0 < H; y0 += 65532) {  // grid.y is 16 bits (65532: a multiple of 4, so every chunk's destination keeps the row phase)
+            const int hh = H - y0 < 65532 ? H - y0 : 65532;
+            hipLaunchKernelGGL(frame_copy_rows_kernel, dim3((unsigned)((ndw_max + 251) / 252), (unsigned)hh), dim3(256), 0, st, src_dev + (long long)y0 * stride,
+                               dst + (long long)y0 * row, hh, row, stride, src_end);
+        }
+    }
     return hipGetLastError();
 }
 
@@ -658,5 +703,11 @@ hipError_t launch_filter(FilterBank* fb, int dim, bool f32vals, int nep50, doubl
     hipLaunchKernelGGL(filter_kernel, dim3(1), dim3(64), 0, st, fb, dim, (int)f32vals, nep50, t, in, out);
     return hipGetLastError();
 }
+
+// What this translation unit was compiled with (vnect_build_info; conv.hip has the twin of this).
+#define VNECT_STR2(x) #x
+#define VNECT_STR(x) VNECT_STR2(x)
+const char* post_build_probes() { return "POST_DBG=" VNECT_STR(POST_DBG) " ARG_SLABS=" VNECT_STR(ARG_SLABS) " ARG_ROWSPLIT=" VNECT_STR(ARG_ROWSPLIT); }
+bool post_probes_off() { return POST_DBG == 0 && ARG_SLABS == 8 && ARG_ROWSPLIT == 1; }
 
 }  // namespace vnect

@@ -80,6 +80,16 @@ __device__ __forceinline__ void stem_put(__bf16* p, float v)
     __hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// end stamps of the profiling twin: every workgroup's end (the host takes the maximum), and workgroup 0's span in both clocks
+__device__ __forceinline__ void stem_prof_end(const StemArgs& a)
+{
+    if (blockIdx.x == 0) {
+        a.prof[25] = (unsigned long long)__builtin_amdgcn_s_memtime();
+        a.prof[26] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    }
+    a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+}
+
 template <bool BF, bool FRAME, bool PROF, bool PAIR = false>
 __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 {
@@ -89,7 +99,10 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
     T* patch = (T*)smem;                                                     // [PH][PW][4]
     float* pooled = smem + STEM_PH * STEM_PW * 4 * sizeof(T) / sizeof(float);  // [h][23][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (PROF && tid == 0 && blockIdx.x == 0) a.prof[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    if (PROF && tid == 0 && blockIdx.x == 0) {
+        a.prof[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        a.prof[24] = (unsigned long long)__builtin_amdgcn_s_memtime();  // shader cycles (kernels.h: PROF_SLOTS)
+    }
 
     // ---- tile geometry (uniform) ---------------------------------------------------------------------------------------
     const int tile = blockIdx.x, c = tile & 3, gi = tile >> 2;
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
                 }
             }
         }
-        if (PROF && tid == 0 && blockIdx.x < PROF_WGS) a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        if (PROF && tid == 0 && blockIdx.x < PROF_WGS) stem_prof_end(a);
         return;
     }
     // ---- 4. the pooled tile: rows r0 .. r1 - 1, columns 23 c .. 23 c + 22 of image sI, 64 channels (16 units of 4) ---------------
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
         T* dst = (T*)a.out + (((long long)sI * 92 + r0 + pr) * 92 + STEM_TW * c + pc) * 64 + u * 4;
         store_wt((tx4*)dst, __builtin_convertvector(v, tx4));
     }
-    if (PROF && tid == 0 && blockIdx.x < PROF_WGS) a.prof_end[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    if (PROF && tid == 0 && blockIdx.x < PROF_WGS) stem_prof_end(a);
 }
 
 hipError_t stem_setup()

@@ -56,6 +56,24 @@ class Group:
         if self._dist:
             self._dist.barrier()
 
+    def host_handoff(self, key, release, timeout_s=900.0):
+        """A HOST-side rendezvous: the releasing rank sets `key` in the process group's store, every other rank blocks on it in a
+        socket wait -- no collective is enqueued, so the waiting ranks' GPUs stay idle (an "nccl" barrier would park a spinning
+        kernel on each of them: bench.py's same-job N = 1 reference wants the other seven GPUs drawing idle power).  Returns how it
+        waited ("store", or "none" for a world of one / a backend without a store: the caller's barrier behind it still orders things)."""
+        if not self._dist:
+            return "none"
+        try:
+            import datetime
+            store = self._dist.distributed_c10d._get_default_store()
+            if release:
+                store.set("vnect/" + key, b"1")
+            else:
+                store.wait(["vnect/" + key], datetime.timedelta(seconds=timeout_s))
+            return "store"
+        except Exception:   # noqa: an older torch without the accessor: fall through to the caller's barrier
+            return "none"
+
     def count_ranks(self):
         """The world size as the backend itself sees it: SUM of 1 over all ranks through a real all-reduce (on the GPUs with
         "nccl" == RCCL).  bench.py reports it, so an N > 1 line says what its collective actually spanned."""
@@ -153,3 +171,138 @@ class PyramidJob:
             t += dt
             out = self.handle.infer_resident(i % nslots, t, t + 1e-3)
         return out, t
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Host placement of a rank (round 6): the rank's host thread -- and, through first touch, the pinned buffers the library allocates --
+# on the cores LOCAL to its GPU (/sys/bus/pci/devices/<bdf>/local_cpulist), decided BEFORE the process makes its first GPU call.  One
+# estimator per process is the reference's own model (/root/reference/run_estimator_ps.py:120-129); eight such processes on a
+# two-socket node otherwise sit wherever the scheduler puts them, half of them a socket away from their device.  Everything here
+# reads sysfs only (no HIP call), so it is testable on a CPU-only machine against a fake sysfs tree (tests/test_parallel_gloo.py).
+
+def parse_cpulist(text):
+    """'0-15,128-143' -> [0..15, 128..143] (the kernel's cpulist format; empty / whitespace -> [])."""
+    cpus = set()
+    for part in (text or "").strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            step = 1
+            if ":" in hi:   # the kernel's "lo-hi:used/group" stride form does not occur for cpulists of a device; refuse it loudly
+                raise ValueError("strided cpulist %r" % part)
+            cpus.update(range(int(lo), int(hi) + 1, step))
+        else:
+            cpus.add(int(part))
+    return sorted(cpus)
+
+
+def format_cpulist(cpus):
+    """[0,1,2,3,8,9] -> '0-3,8-9'."""
+    cpus = sorted(set(cpus))
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def gpu_bdfs(sysfs="/sys"):
+    """PCI addresses of the GPUs in the order HIP enumerates them by default: the KFD topology's nodes with SIMDs, ascending node id
+    (`location_id` = bus << 8 | devfn, `domain`).  [] when the machine has no KFD (this container)."""
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return []
+    out = []
+    for n in nodes:
+        props = {}
+        try:
+            for ln in open(os.path.join(base, str(n), "properties")):
+                kv = ln.split()
+                if len(kv) == 2:
+                    props[kv[0]] = kv[1]
+        except OSError:
+            continue   # a node this user may not read (another container's device)
+        if int(props.get("simd_count", "0")) == 0:
+            continue   # a CPU node
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        out.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    return out
+
+
+def visible_order(env=None):
+    """The physical indices behind HIP device ordinals 0, 1, ... when ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    restrict or reorder them (plain integer lists only; None = no restriction; a list by UUID is reported as unknown -> no binding)."""
+    env = os.environ if env is None else env
+    order = None
+    for key in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):   # ROCr filters first, HIP indexes into what is left
+        v = env.get(key)
+        if v is None or not v.strip():
+            continue
+        try:
+            idx = [int(x) for x in v.split(",") if x.strip()]
+        except ValueError:
+            return "unknown"
+        order = idx if order is None else [order[i] for i in idx if i < len(order)]
+    return order
+
+
+def rank_binding(device, sysfs="/sys", env=None, allowed=None):
+    """Where rank's host thread should sit: {"bdf", "numa_node", "local_cpulist", "cpus": [...]} for HIP device ordinal `device`, or
+    {"cpus": None, "reason": ...}.  `allowed` = the process's present affinity (the cgroup / taskset limit): the result is the
+    intersection, and an empty intersection means "leave the thread where it is"."""
+    bdfs = gpu_bdfs(sysfs)
+    if not bdfs:
+        return {"cpus": None, "reason": "no KFD topology under %s (no GPU visible to sysfs)" % sysfs}
+    order = visible_order(env)
+    if order == "unknown":
+        return {"cpus": None, "reason": "*_VISIBLE_DEVICES is not a list of integers: device order unknown"}
+    phys = device if order is None else (order[device] if device < len(order) else None)
+    if phys is None or phys >= len(bdfs):
+        return {"cpus": None, "reason": "device %d is not among the %d GPU(s) sysfs shows" % (device, len(bdfs))}
+    bdf = bdfs[phys]
+    d = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+    try:
+        text = open(os.path.join(d, "local_cpulist")).read().strip()
+    except OSError:
+        return {"cpus": None, "bdf": bdf, "reason": "no local_cpulist for %s" % bdf}
+    try:
+        numa = int(open(os.path.join(d, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        numa = None
+    local = parse_cpulist(text)
+    cpus = local if allowed is None else [c for c in local if c in set(allowed)]
+    if not cpus:
+        return {"cpus": None, "bdf": bdf, "numa_node": numa, "local_cpulist": text,
+                "reason": "none of the device's local cores is in this process's affinity mask"}
+    return {"cpus": cpus, "bdf": bdf, "numa_node": numa, "local_cpulist": text}
+
+
+def bind_rank(device, enable=True, sysfs="/sys"):
+    """Bind THIS process to the cores local to HIP device `device`; call it before the first GPU call (before the HIP library is
+    loaded: its helper threads and pinned allocations inherit the mask).  Returns the report bench.py prints in `ranks[]`."""
+    try:
+        before = sorted(os.sched_getaffinity(0))
+    except AttributeError:   # not Linux
+        return {"bound": False, "reason": "no sched_getaffinity on this platform"}
+    if not enable:
+        return {"bound": False, "reason": "--no-bind", "affinity": format_cpulist(before), "n_cpus": len(before)}
+    b = rank_binding(device, sysfs=sysfs, allowed=before)
+    rep = {k: b[k] for k in ("bdf", "numa_node", "local_cpulist") if b.get(k) is not None}
+    if not b["cpus"]:
+        rep.update(bound=False, reason=b["reason"], affinity=format_cpulist(before), n_cpus=len(before))
+        return rep
+    try:
+        os.sched_setaffinity(0, b["cpus"])
+    except OSError as e:
+        rep.update(bound=False, reason="sched_setaffinity: %s" % e, affinity=format_cpulist(before), n_cpus=len(before))
+        return rep
+    now = sorted(os.sched_getaffinity(0))
+    rep.update(bound=True, affinity=format_cpulist(now), n_cpus=len(now), narrowed_from=len(before))
+    return rep
