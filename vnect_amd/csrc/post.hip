@@ -455,19 +455,6 @@ __global__ __launch_bounds__(128) void joints_kernel(const ArgPartial* __restric
     joints_body<SMAX>(part, maps, geo, fb, f2, f3, scaler, off, dyn, nep50, out);
 }
 
-// Both in ONE launch (round 2): the 168 arg-max workgroups publish their partials write-through and take an agent-scope ticket; the
-// workgroup whose ticket comes last -- every partial is then in memory -- runs the joints stage (filters, read-off, un-mapping) with
-// its first 105 threads.  Nobody waits: the other workgroups are gone by then.  The hand-off is, cell for cell, the first row of
-// MI355X_MICROARCH.md's table of hand-offs measured valid with `sc1` loads in place of an acquire: ONE lane per storing workgroup stores
-// its bytes `sc1` (8- and 4-byte), waits vmcnt(0), adds to ONE unsharded agent-scope counter; the workgroup whose add came last loads
-// (`sc1`, 8- and 4-byte) only after its add has returned, its other waves behind a workgroup barrier.  An explicit release / acquire
-// pair instead (buffer_wbl2 sc1 / buffer_inv sc1) is priced at ~1.7 us EACH in the same guide, on the critical path of a kernel
-// that is nothing but a chain of round trips -- so the relaxed form stays, and this comment is what keeps it honest: any change
-// to the store / wait / add / load sequence must be checked against that table again.
-// Round 3: every workgroup requests what the joints stage needs that does not depend on the arg-max (the first 105 threads' filter
-// states and un-mapping constants -> registers) before anything else, so the last arriver starts no memory round trip for them;
-// the resize geometry travels in the kernel arguments (MergeGeo) and every table entry is computed where it is used; on a pyramid-sharded handle a frame whose exchange failed (dyn.xfail) skips the
-// joints stage -- the filter banks do not advance on stale maps -- and reports status 1.
 // The joints stage of post_kernel, spread over the last arriver's six waves (round 5; joints_body above is the 128-thread form of the
 // stand-alone joints_kernel and gives the same bits).  The one-wave form cost ~7 of the launch's 15 us: ~2 500 instructions on ONE
 // wave's dependent stream -- 4 merged cells x 3 scales of axis arithmetic per read-off, two filter steps with their f64 divisions --

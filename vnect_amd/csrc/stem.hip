@@ -482,7 +482,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 #pragma unroll
                 for (int q = 0; q < NQ; q++) Bc[q] = Bn[q];
             }
-                    if constexpr (BF) {
+            if constexpr (BF) {
                 // the wave's 32 x 160 tile, 16 bytes per lane and store: row = tile row -> its pixel (pixtab; rows past the tile go to the
                 // tensors' slack pixels), 20 units per row -- wave half 0: 8 units of res2a_branch2a's 64 channels, then channels 0..95 of
                 // res2a_branch1; half 1: channels 96..255 -- whole 128-, 192- and 320-byte runs
