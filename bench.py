@@ -495,9 +495,13 @@ def main():
                 st1.append(time.perf_counter())
             torch.cuda.synchronize()
             e1 = time.perf_counter() - t0
+            np1 = min(max(args.steps // 4, 10), 100)
+            tim1 = profile(lambda n: run(h1, n), h1, np1)   # the same device-side figures the per-rank reports carry, for the solo loop
             n1_same_job = {"value": round(args.steps / e1, 2), "unit": "frames/s", "ms_per_step": round(e1 / args.steps * 1e3, 4),
                            "steps": args.steps, "warmup": args.warmup, "rank": 0, "device": local_rank,
                            "latency_ms": latency_summary(np.diff(np.array(st1)) * 1e3, args.steps),
+                           "conv_stack_ms": round(tim1["conv_slot_ms"] / np1, 4), "frame_ms_hip_events": round(tim1["total_ms"] / np1, 4),
+                           "shader_clock_mhz": None if not tim1.get("shader_clock_mhz") else round(tim1["shader_clock_mhz"], 1),
                            "what": "rank 0's synchronous 3-scale loop run alone inside this job, before the %d-rank region; the other ranks "
                                    "wait on the rendezvous store (host-side: their GPUs are idle)" % args.gpus}
             if args.pyramid:

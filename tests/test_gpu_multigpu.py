@@ -124,6 +124,12 @@ def _check_self_explaining(d, n, same_device, replicas):
             assert hb["bdf_is_the_hip_device"] is True, hb   # the sysfs chain and HIP name the same device
     n1 = d["n1_same_job"]
     assert n1 and n1["rank"] == 0 and n1["value"] > 0 and n1["steps"] == d["steps"] and n1["latency_ms"]["p50"] > 0
+    assert 0 < n1["conv_stack_ms"] <= n1["frame_ms_hip_events"] * 1.05 and 800 < n1["shader_clock_mhz"] < 2600, n1
+    # ... and tools/explain_scale.py can read the line (the attribution an unattended run gets)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import explain_scale
+    text = explain_scale.explain(d)
+    assert "attribution:" in text and ("same-job N = 1 loop" in text), text
     # (whether a rank COULD bind depends on what sysfs the container shows: a rank that could not says why -- never a parity failure)
     assert all(r["host_binding"]["bound"] or r["host_binding"].get("reason") for r in pr), [r["host_binding"] for r in pr]
     assert "probes_off=1" in d["build"] and "test_hooks=0" in d["build"]
