@@ -517,7 +517,7 @@ def main():
 
     # pipelined rate of the same stream (three frames in flight on three lanes: they overlap, only the filter kernels stay
     # ordered), reported beside the synchronous one
-    pipelined = pcie = pinned = two_streams = None
+    pipelined = pcie = pinned = two_streams = call_surface = None
     if not args.no_aux and not args.pyramid:
         barrier()
         p0 = time.perf_counter()
@@ -531,28 +531,40 @@ def main():
             h.collect()
         torch.cuda.synchronize()
         pipelined = args.steps / (time.perf_counter() - p0)
-        # the same synchronous loop fed from HOST memory (vnect_infer: a pageable 406 KB frame crosses PCIe every step) --
-        # the rate a caller of VNectEstimator.__call__ sees; never `value` (whose frames are resident in HBM)
-        nh = max(args.steps // 3, 20)
-        for i in range(5 + nh):
-            if i == 5:
-                torch.cuda.synchronize()
-                q0 = time.perf_counter()
-            clock[0] += 1 / 30
-            h.infer(host_frames[i % nslots], clock[0], clock[0] + 1e-3)
-        pcie = nh / (time.perf_counter() - q0)
-        # ... and from the handle's PINNED capture buffers (vnect_frame_buffer: where a capture pipeline would put its frames): the same
-        # call, the frame still crosses PCIe every step, but no CPU copy comes first
+        # The CALL-SURFACE rate (VNectEstimator.__call__ takes host memory, /root/reference/src/estimator.py:97-99): the same synchronous
+        # loop fed through vnect_infer -- from pageable numpy memory (a CPU copy into the pinned staging buffer, then the copy kernel), from
+        # the handle's PINNED capture buffers (vnect_frame_buffer: no CPU copy), and, as the yardstick, from resident frames -- measured
+        # INTERLEAVED in rounds of 20 frames, >= 200 frames per variant, medians of the per-frame latency: the variants are 0.5-1 % apart
+        # and a box drifts by more than that between two sequential 20-frame legs (round 5's figures).  Never `value`.
         bufs = [h.frame_buffer(i, 368, 368) for i in range(2)]
         for i in range(2):
             bufs[i][...] = host_frames[i]
-        for i in range(5 + nh):
-            if i == 5:
-                torch.cuda.synchronize()
-                q0 = time.perf_counter()
+        nh = max(args.steps, 200)
+        cs_lat = {"resident": [], "pageable": [], "pinned": []}
+
+        def cs_frame(v, i):
             clock[0] += 1 / 30
-            h.infer(bufs[i % 2], clock[0], clock[0] + 1e-3)
-        pinned = nh / (time.perf_counter() - q0)
+            if v == "resident":
+                return h.infer_resident(1 + i % (nslots - 1), clock[0], clock[0] + 1e-3)   # (slot 0 is vnect_infer's staging slot)
+            return h.infer((host_frames if v == "pageable" else bufs)[i % 2], clock[0], clock[0] + 1e-3)
+
+        rounds = (nh + 19) // 20
+        for rd in range(rounds):
+            order = ("resident", "pageable", "pinned") if rd % 2 == 0 else ("pinned", "pageable", "resident")
+            for v in order:
+                for i in range(2):
+                    cs_frame(v, i)                       # (two frames to settle into the variant: untimed)
+                for i in range(20):
+                    q0 = time.perf_counter()
+                    cs_frame(v, i)
+                    cs_lat[v].append((time.perf_counter() - q0) * 1e3)
+        cs_med = {v: float(np.median(np.array(x))) for v, x in cs_lat.items()}
+        pcie, pinned = 1e3 / cs_med["pageable"], 1e3 / cs_med["pinned"]
+        call_surface = {"frames_per_variant": 20 * rounds, "method": "interleaved rounds of 20 synchronous frames per variant, rate of the median frame",
+                        "median_ms": {v: round(x, 4) for v, x in cs_med.items()},
+                        "frames_per_s": {v: round(1e3 / x, 2) for v, x in cs_med.items()},
+                        "vs_resident_percent": {v: round(100 * (cs_med["resident"] / x - 1), 2) for v, x in cs_med.items()},
+                        "extra_us_per_frame": {v: round((x - cs_med["resident"]) * 1e3, 1) for v, x in cs_med.items()}}
         for k in range(nslots):  # vnect_infer stages its frame in slot 0: restore the resident set
             h.upload_frame(k, host_frames[k])
         # two independent video streams sharing this GPU (two handles, two host threads): what the idle CUs between the
@@ -676,6 +688,7 @@ def main():
             "rccl_library": rccl_lib,
             "pcie_inclusive_frames_per_s_per_gpu": None if pcie is None else round(pcie, 2),
             "pcie_inclusive_from_pinned_capture_buffer_frames_per_s_per_gpu": None if pinned is None else round(pinned, 2),
+            "call_surface": call_surface,
             "pipelined_frames_per_s_per_gpu": None if pipelined is None else round(pipelined, 2),
             "two_streams_on_one_gpu_frames_per_s": None if two_streams is None else round(two_streams, 2),
             "three_streams_on_one_handle_frames_per_s": None if streams3 is None else round(streams3, 2),

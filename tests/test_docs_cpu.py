@@ -40,3 +40,26 @@ def test_design_is_short_and_quotes_the_headers_abi_version():
     assert ("ABI v%d" % v) in _text("DESIGN.md") and ("ABI v%d" % v) in _text("INTEGRATION.md")
     from vnect_amd import _native
     assert _native.ABI_VERSION == v
+
+
+def test_rates_quoted_in_integration_are_the_committed_bench_line():
+    """INTEGRATION.md quotes frames/s figures in ONE table, every row naming the key of the committed bench line it comes from
+    (tools/sync_docs_rates.py rewrites the numbers from the file): a figure that no longer matches the line it cites fails here -- round 5's
+    text still carried round 4's numbers."""
+    import json
+    text = _text("INTEGRATION.md")
+    m = re.search(r"committed as `(profiles/r\d\d_bench_line\.json)`", text)
+    assert m, "the table of rates must name the bench line it quotes"
+    line = json.load(open(os.path.join(ROOT, m.group(1))))
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d\d_bench_line\.json$", f))[-1]
+    assert m.group(1) == "profiles/" + newest, "INTEGRATION.md quotes %s, the newest committed line is %s" % (m.group(1), newest)
+    rows = re.findall(r"^\|[^|]*\| `([a-z0-9_.]+)` \| ([0-9 .]+) \|$", text, re.M)
+    assert len(rows) >= 10, rows
+    for key, num in rows:
+        v = line
+        for k in key.split("."):
+            v = v[k]
+        assert abs(float(num.replace(" ", "")) - float(v)) <= 0.006, (key, num, v)
+    # no other sentence of the file carries a bare frames/s figure of its own (percentages and microseconds are fine)
+    body = text[:text.index("## Rates quoted in this file")]
+    assert not re.search(r"\d \d{3}(?:\.\d+)? frames/s", body), re.findall(r"[^.]*\d \d{3}(?:\.\d+)? frames/s[^.]*", body)[:3]

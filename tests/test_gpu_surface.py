@@ -625,4 +625,17 @@ def test_bench_line_contract():
     assert d["bf16"]["pipelined_frames_per_s_per_gpu"] > 0 and d["fp32_split"]["pipelined_frames_per_s_per_gpu"] > 0 and d["pipelined_frames_per_s_per_gpu"] > 0
     assert 0 < d["pcie_inclusive_frames_per_s_per_gpu"] < 1.02 * d["value"] and 0 < d["pcie_inclusive_from_pinned_capture_buffer_frames_per_s_per_gpu"] < 1.02 * d["value"]
     assert d["fp32_split"]["value"] > 0 and d["fp32_split"]["roofline"]["bound"] == "mfma"
+    # round 6: the call-surface legs are interleaved (>= 200 frames per variant whatever --steps says), medians; a short run carries its
+    # per-frame latencies and the median-based rate; the line says how the library was built and what the (one) rank did
+    cs = d["call_surface"]
+    assert cs["frames_per_variant"] >= 200 and set(cs["frames_per_s"]) == {"resident", "pageable", "pinned"}
+    assert cs["frames_per_s"]["pinned"] <= 1.01 * cs["frames_per_s"]["resident"] and cs["frames_per_s"]["pageable"] <= 1.01 * cs["frames_per_s"]["resident"]
+    assert 0 < cs["extra_us_per_frame"]["pinned"] < 60 and 0 < cs["extra_us_per_frame"]["pageable"] < 80, cs
+    assert abs(d["pcie_inclusive_frames_per_s_per_gpu"] - cs["frames_per_s"]["pageable"]) < 0.02
+    for leg in (d, d["bf16"], d["fp32_split"]):
+        lm = leg["latency_ms"]
+        assert len(lm["frames_ms"]) == 12 and abs(lm["value_from_median"] - 1e3 / lm["p50"]) < 0.5
+    assert "probes_off=1" in d["build"] and "test_hooks=0" in d["build"] and d["n1_same_job"] is None
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and 800 < pr[0]["shader_clock_mhz"] < 2600 and pr[0]["host_binding"]["bound"] is False
     assert d["rccl_ranks"] == 1 and d["ranks"][0]["device"] == 0 and d["launched_by"] == "single process"

@@ -290,6 +290,202 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 1) void gemm_tile_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Shape P (round 6, second question): 112 x 16 tiles, FOUR in-workgroup K groups -- for the launches of the 23x23 stage whose N is small
+// and whose K is long (res4*_branch2a: N = 256, K = 1 024; res4*_branch2b: N = 256, K = 2 304), which run as 200 tiles of 64 x 32 x 2 on
+// 256 CUs (0.78 of the chip) today.  15 x 16 = 240 tiles, one round, 1 792 outputs per CU instead of 2 048.  Their epilogue moves 1.6 MB
+// (no shortcut), so the 16x16 layout's half-line stores -- what killed 112 x 64 on the N = 1 024 launches -- are small change here.
+// Every consumer wave holds seven 16x16 accumulators (all seven row blocks of the one column block) and takes a QUARTER of every
+// chunk's K: wave w reads the 16-byte units 2 w, 2 w + 1 of each row (ds_read_b64: lane (r, kq) gets k = 8 w + 2 kq + {0, 1}), 14 MFMAs and
+// 8 reads per chunk; after the K loop the four partial sums meet in LDS.  out[m][n] = relu(sum_k A[m][k] W[n][k] + bias[n]).
+template <int NS, bool EPI>
+__global__ __launch_bounds__(512, 1) void gemm_p_kernel(const GArgs a)
+{
+    constexpr int BM = 112, RB = 7, ARB = 4, BROW0 = ARB * 32, ROWS = BROW0 + 32, PER = ARB + 1, STAGE = ROWS * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    int item;
+    {
+        const int items = a.tiles_m * a.tiles_n, id = blockIdx.x, xcd = id & 7, l = id >> 3;
+        const int qd = items >> 3, rm = items & 7;
+        item = __builtin_amdgcn_readfirstlane((xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + l);
+    }
+    const int tile_m = item / a.tiles_n, tile_n = item - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * 16;
+    const int G = a.K >> 5;
+    if (producer) {
+        __builtin_amdgcn_s_setprio(3);
+        const srd_t srdA = make_srd(a.A), srdB = make_srd(a.W);
+        unsigned a_vo[ARB], b_vo;
+        const int srow = tid >> 3;
+        const int unit = (tid & 7) ^ ((tid >> 4) & 7);
+#pragma unroll
+        for (int i = 0; i < ARB; i++) {
+            const int row = 32 * i + srow;
+            a_vo[i] = (row < BM && m0 + row < a.M) ? (unsigned)(((m0 + row) * a.K + unit * 4) * 4) : 0x80000000u;
+        }
+        b_vo = srow < 16 ? (unsigned)(((n0 + srow) * a.K + unit * 4) * 4) : 0x80000000u;   // rows 16 .. 31 of the B block: nothing fetched
+        int nis = 0, istage = 0;
+        unsigned so = 0;
+        auto put = [&]() __attribute__((always_inline)) {
+            float* sb = smem + __builtin_amdgcn_readfirstlane(istage) * STAGE + wave * 256;
+            const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)so);
+#pragma unroll
+            for (int i = 0; i < ARB; i++) bload_lds(srdA, sb + i * 1024, a_vo[i], u);
+            bload_lds(srdB, sb + BROW0 * 32, b_vo, u);
+            so += 128, istage = istage + 1 == NS ? 0 : istage + 1, nis++;
+        };
+        auto wait_landed = [&](int young) __attribute__((always_inline)) {
+            switch (young) {
+                case 1: wait_vm<PER>(); break;
+                case 2: wait_vm<2 * PER>(); break;
+                case 3: wait_vm<3 * PER>(); break;
+                case 4: wait_vm<4 * PER>(); break;
+                default: wait_vm<0>(); break;
+            }
+        };
+        put();
+        if (G > 1) put();
+        wait_landed(nis - 1);
+        __builtin_amdgcn_s_barrier();
+        if (G > 2) put();
+        for (int g = 0; g < G; g++) {
+            const int young = nis - g - 2;
+            wait_landed(young > 0 ? (young < NS - 3 ? young : NS - 3) : 0);
+            __builtin_amdgcn_s_barrier();
+            const int target = G < g + NS ? G : g + NS;
+            while (nis < target) put();
+        }
+        // the producers stay for the two barriers of the consumers' reduction (a wave that has ended no longer counts, but being there is simpler to reason about)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    cgfloat* bias = (cgfloat*)a.bias;
+    gfloat* out = (gfloat*)a.out;
+    int foA[RB], foB;
+    {
+        const int kq = lane >> 4, u = 2 * wave + (kq >> 1), half = kq & 1;
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            const int row = rb * 16 + (lane & 15);
+            foA[rb] = row * 32 + ((u ^ ((row >> 1) & 7)) * 4) + half * 2;
+        }
+        const int rowB = BROW0 + (lane & 15);
+        foB = rowB * 32 + ((u ^ ((rowB >> 1) & 7)) * 4) + half * 2;
+    }
+    struct Frag { f32x2 a[RB], b; } F0, F1;
+    f32x4 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + (lane & 15);
+    const float bv = bias[n];
+    int stage = 0;
+    __builtin_amdgcn_s_barrier();  // chunk 0 visible
+    F0.b = *(const f32x2*)(smem + foB);
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++) F0.a[rb] = *(const f32x2*)(smem + foA[rb]);
+    auto step = [&](Frag& cur, Frag& nxt, bool more) __attribute__((always_inline)) {
+        const int nstage = stage + 1 == NS ? 0 : stage + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float* S = smem + nstage * STAGE;
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[rb][e], cur.b[e], acc[rb], 0, 0, 0);
+                const int i = e * RB + rb;   // 0 .. 13: the 8 reads of the next chunk behind MFMAs 0, 1, 3, 4, 6, 7, 9, 10
+                if (i % 3 != 2 && (i - i / 3) < RB + 1) {
+                    const int r = i - i / 3;
+                    if (more) {
+                        if (r == 0) nxt.b = *(const f32x2*)(S + foB);
+                        else nxt.a[r - 1] = *(const f32x2*)(S + foA[r - 1]);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        stage = nstage;
+    };
+    for (int g = 0; g < G; g += 2) {
+        step(F0, F1, g + 1 < G);
+        if (g + 1 < G) step(F1, F0, g + 2 < G);
+    }
+    // the four K quarters meet in LDS (the ring is idle: every chunk has been consumed).  Wave w finishes row blocks w and w + 4 (w < 3) /
+    // block 3 (w = 3): every wave stores the partials of the blocks it does NOT finish, lane-linear 16-byte slots, then adds the three others'
+    float* part = smem;   // [writer wave][block][lane] x 16 B = 4 x 7 x 1 KiB
+    __builtin_amdgcn_s_barrier();   // (all consumers are past their last fragment read)
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+        if ((rb & 3) != wave) *(f32x4*)(part + ((wave * RB + rb) * 64 + lane) * 4) = acc[rb];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++) {
+        if ((rb & 3) != wave) continue;   // (wave-uniform)
+        f32x4 sum = acc[rb];
+        // fixed order: K quarters 0, 1, 2, 3 (the own one in its place), so the result does not depend on which wave finishes the block
+        f32x4 q[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) q[w] = w == wave ? sum : *(const f32x4*)(part + ((w * RB + rb) * 64 + lane) * 4);
+        sum = ((q[0] + q[1]) + q[2]) + q[3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = m0 + rb * 16 + 4 * (lane >> 4) + i;
+            float o = __builtin_fmaxf(sum[i] + bv, 0.f);
+            if (m < a.M && (EPI || __builtin_bit_cast(unsigned, o) == 0x7fc12345u)) put_f32(out + (unsigned)(m * a.N + n), o);
+        }
+    }
+}
+
+template <int NS, bool EPI = true>
+static double run_p(const char* name, GArgs a, int reps, std::vector<float>& hout, const std::vector<float>& ref, const std::vector<int>& samples)
+{
+    const size_t lds = (size_t)NS * (128 + 32) * 128;
+    auto k = gemm_p_kernel<NS, EPI>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipFuncAttributes fa;
+    CK(hipFuncGetAttributes(&fa, (const void*)k));
+    a.tiles_m = (a.M + 111) / 112, a.tiles_n = a.N / 16;
+    const int grid = a.tiles_m * a.tiles_n;
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipMemsetAsync(a.out, 0, (size_t)a.M * a.N * 4, st));
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    CK(hipMemcpy(hout.data(), a.out, (size_t)a.M * a.N * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0, maxref = 0;
+    if (EPI)
+        for (size_t s = 0; s < samples.size(); s++) maxerr = std::max(maxerr, (double)fabsf(hout[samples[s]] - ref[s])), maxref = std::max(maxref, (double)fabsf(ref[s]));
+    std::vector<double> us;
+    for (int rep = 0; rep < 7; rep++) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        us.push_back(ms * 1e3 / reps);
+    }
+    std::sort(us.begin(), us.end());
+    const double flops = 2.0 * a.M * a.N * a.K;
+    printf("  %-5s 112 x 16 x 4 K groups: %4d workgroups (%.2f per CU), %3d VGPRs, %6zu B LDS: %6.2f us per launch (median of 7 x %d back-to-back; min %.2f max %.2f), "
+           "%5.1f TFLOP/s, max |err| %.2e of max |ref| %.2f\n",
+           name, grid, grid / 256.0, fa.numRegs, lds, us[3], reps, us[0], us[6], flops / (us[3] * 1e-6) / 1e12, maxerr, maxref);
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    CK(hipStreamDestroy(st));
+    return us[3];
+}
+
 template <int BM, int NS, bool EPI = true>
 static double run(const char* name, GArgs a, int reps, std::vector<float>& hout, const std::vector<float>& ref, const std::vector<int>& samples)
 {
@@ -385,6 +581,52 @@ int main(int argc, char** argv)
         const double k112 = run<112, 5, false>("T112-", a, reps, hout, ref, samples);
         printf("  K loop + cold start: 64 x 64 %.2f us, 112 x 64 %.2f us (%+.2f); epilogue: 64 x 64 %.2f us, 112 x 64 %.2f us (%+.2f)\n", k64, k112, k112 - k64,
                t64 - k64, t112 - k112, (t112 - k112) - (t64 - k64));
+        CK(hipFree(dA));
+        CK(hipFree(dW));
+        CK(hipFree(db));
+        CK(hipFree(dr));
+        CK(hipFree(dout));
+    }
+    // ---- second question: the small-N, long-K 1x1 launches (res4*_branch2a: M = 1 587, N = 256, K = 1 024; no shortcut) as 112 x 16 x 4 ----
+    {
+        const int N2 = 256, K = 1024;
+        std::vector<float> hA((size_t)M * K), hW((size_t)N2 * K), hb(N2), hr((size_t)M * N2, 0.f), hout((size_t)M * N2);
+        unsigned s = 777u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : hA) v = rnd();
+        for (auto& v : hW) v = rnd() * 0.1f;
+        for (auto& v : hb) v = rnd();
+        std::vector<int> samples;
+        std::vector<float> ref;
+        for (int i = 0; i < 4000; i++) {
+            s = s * 1664525u + 1013904223u;
+            const int m = i < 64 ? M - 1 - i : (int)((s >> 8) % M);
+            s = s * 1664525u + 1013904223u;
+            const int n = (int)((s >> 8) % N2);
+            double acc = 0;
+            for (int k = 0; k < K; k++) acc += (double)hA[(size_t)m * K + k] * hW[(size_t)n * K + k];
+            acc += hb[n];
+            samples.push_back(m * N2 + n), ref.push_back((float)std::max(acc, 0.0));
+        }
+        GArgs a{};
+        float *dA, *dW, *db, *dr, *dout;
+        CK(hipMalloc(&dA, hA.size() * 4 + 65536));
+        CK(hipMalloc(&dW, hW.size() * 4));
+        CK(hipMalloc(&db, N2 * 4));
+        CK(hipMalloc(&dr, hr.size() * 4));
+        CK(hipMalloc(&dout, hr.size() * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), N2 * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(dr, 0, hr.size() * 4));
+        a.A = dA, a.W = dW, a.bias = db, a.resid = dr, a.out = dout, a.M = M, a.N = N2, a.K = K;
+        printf("M = %d, N = %d, K = %d (res4*_branch2a; the product runs it as 200 tiles of 64 x 32 x 2: 9.5 us of execution, ~12.3 us per back-to-back launch): ideal %.2f us\n",
+               M, N2, K, 2.0 * M * N2 * K / 157.3e12 * 1e6);
+        for (int round = 0; round < 2; round++) {
+            run<64, 5>("T64", a, reps, hout, ref, samples);    // (100 tiles of 64 x 64: the harness's yardstick, not a plan anybody would use)
+            run_p<5>("P", a, reps, hout, ref, samples);
+        }
+        run_p<5, false>("P-", a, reps, hout, ref, samples);
         CK(hipFree(dA));
         CK(hipFree(dW));
         CK(hipFree(db));

@@ -153,7 +153,8 @@ class VNectEstimator:
     # -- pipelined use (additive; the reference's loop is strictly one frame at a time) --------------------------------
     def submit(self, img_input, timestamp=None):
         """Queue a frame and return at once; at most ``max(lanes, 2)`` may be in flight.  With ``lanes=2`` / ``3`` the frames
-        overlap on the GPU (+28 % / +38 % frames/s for one video stream, at the price of their latency); ``collect()`` returns
+        overlap on the GPU (+29 % frames/s for one video stream at three lanes -- `pipelined_frames_per_s_per_gpu` against `value` in
+        profiles/r06_bench_line.json -- at the price of their latency); ``collect()`` returns
         results in order and they are bit-identical to calling the estimator frame by frame."""
         t2d, t3d = self._stamps(timestamp)
         slot = self._submitted % 4
