@@ -582,6 +582,47 @@ def test_pinned_crops_at_every_byte_alignment_reach_the_device_intact(weights):
     h.close()
 
 
+def test_timings_carry_the_shader_clock_and_accept_the_v5_struct(weights):
+    """ABI v6: vnect_timings ends with shader_cycles / shader_ticks -- workgroup 0 of every conv launch of the profiling twin stamps the
+    shader-cycle counter (s_memtime) beside the 100 MHz clock at its start and its end; 100 * cycles / ticks is the clock the chip held while
+    the launches ran (bench.py reports it per rank).  A caller compiled against ABI v5 passes the 56-byte struct and gets the v5 fields,
+    nothing written behind them."""
+    from vnect_amd import _native
+    from tests import helpers
+    h = _native.Handle(BASELINE_SCALES, num_frame_slots=2)
+    h.set_weights(weights)
+    h.finalize()
+    h.upload_frame(0, helpers.synth_frame(9400))
+    for k in range(5):
+        h.infer_resident(0, T0 + k / 30, T0 + k / 30 + 0.001)
+    h.set_profiling(True)
+    h.reset_timings()
+    n = 12
+    for k in range(n):
+        h.infer_resident(0, T0 + 1 + k / 30, T0 + 1 + k / 30 + 0.001)
+    t = h.timings()
+    h.set_profiling(False)
+    assert t["frames"] == n and t["conv_launches"] == 40
+    assert 1500 < t["shader_clock_mhz"] < 2500, t          # MI355X: 2.4 GHz peak engine clock
+    # workgroup 0 lives from a launch's start to (about) its end: its spans add up to most of the conv launches' own durations
+    span_ms = t["shader_ticks"] * 1e-5
+    assert 0.5 * t["conv_ms"] < span_ms <= 1.02 * t["conv_ms"], (span_ms, t["conv_ms"])
+
+    class TimingsV5(C.Structure):
+        _fields_ = _native.Timings._fields_[:-2] + [("guard", C.c_double * 2)]
+    v5 = TimingsV5()
+    v5.struct_size = 56
+    v5.guard[0], v5.guard[1] = -1.0, -2.0
+    L = _native.lib()
+    rc = L.vnect_get_timings(h._h, C.cast(C.byref(v5), C.POINTER(_native.Timings)))
+    assert rc == 0 and v5.struct_size == 56 and v5.frames == n and abs(v5.conv_slot_ms - t["conv_slot_ms"]) < 1e-9
+    assert (v5.guard[0], v5.guard[1]) == (-1.0, -2.0)       # nothing written past the caller's struct
+    bad = _native.Timings()
+    bad.struct_size = 64
+    assert L.vnect_get_timings(h._h, C.byref(bad)) == _native.E_ARG
+    h.close()
+
+
 # ------------------------------------------------------------------------------------------ the bench line's contract
 def test_bench_line_contract():
     """`python bench.py` as the driver runs it (N = 1): ONE JSON line on stdout with the contract's keys -- metric / value / unit /
