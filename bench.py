@@ -378,11 +378,9 @@ def main():
         pci = torch.cuda.get_device_properties(local_rank).pci_bus_id
     except Exception:
         pci = None
-    if binding.get("bdf") and pci is not None:   # the sysfs chain (KFD node order) and HIP agree on which device this is?
-        try:
-            binding["bdf_is_the_hip_device"] = int(binding["bdf"].split(":")[1], 16) == int(pci)
-        except (ValueError, IndexError):
-            pass
+    # the sysfs chain (KFD node order) and HIP agree on which device this is?  If not, the thread moves to the right device's cores now
+    from vnect_amd.parallel import rebind_by_bus
+    binding = rebind_by_bus(binding, pci)
     placement = grp.all_gather_object({"rank": rank, "device": local_rank, "pci_bus_id": pci, "pid": os.getpid(), "host_binding": binding})
     weights = synthetic_weights()
     nslots = 8
@@ -445,7 +443,7 @@ def main():
         grp.barrier()
         torch.cuda.synchronize()
 
-    own = [0.0]
+    own = [0.0, 0.0]
 
     def timed(hh, steps, warmup):
         """W untimed frames, then EXACTLY `steps` synchronous frames between barrier + synchronize; MAX over ranks."""
@@ -459,6 +457,7 @@ def main():
             stamps.append(time.perf_counter())  # per-frame latency distribution (median + p95)
         own[0] = stamps[-1] - t0    # this rank's own time for its K frames (before it waits for the others)
         barrier()
+        own[1] = time.perf_counter() - t0 - own[0]   # what the closing barrier + synchronize took on this rank (INSIDE the region by the contract)
         elapsed = grp.max_over_ranks(time.perf_counter() - t0)
         assert np.all(np.isfinite(j2)) and np.all(np.isfinite(j3))
         return elapsed, np.diff(np.array(stamps)) * 1e3
@@ -512,7 +511,7 @@ def main():
         grp.barrier()
 
     elapsed, lat = timed(h, args.steps, args.warmup)
-    own_elapsed = own[0]
+    own_elapsed, own_close = own[0], own[1]
     dump_joints(h, ("pyramid_" + args.exchange) if args.pyramid else "replica")
 
     # pipelined rate of the same stream (three frames in flight on three lanes: they overlap, only the filter kernels stay
@@ -615,10 +614,13 @@ def main():
     nprof = min(max(args.steps // 4, 10), 100)
     # every rank profiles its own handle (no collective inside a replica's frames; a pyramid job's inferences contain the exchange, so
     # every rank must take part anyway): per-rank conv-stack time and the shader clock each GPU held are what explains an N > 1 curve
-    def rank_report(lat_, own_, tim_):
+    def rank_report(lat_, own_, tim_, close_):
         return grp.all_gather_object({
             "rank": rank, "device": local_rank,
             "frames_per_s": round(args.steps / own_, 2), "own_elapsed_s": round(own_, 5),
+            # the closing barrier + torch.cuda.synchronize() of the timed region (the contract puts it inside): what separates `value` from the
+            # frames' own rate in a short window; at N > 1 it also holds this rank's wait for the slowest one
+            "closing_barrier_us": round(close_ * 1e6, 1),
             "latency_ms": {k: v for k, v in latency_summary(lat_, args.steps).items() if k != "frames_ms"},
             "conv_stack_ms": round(tim_["conv_slot_ms"] / nprof, 4), "conv_first_to_last_ms": round(tim_["net_ms"] / nprof, 4),
             "frame_ms_hip_events": round(tim_["total_ms"] / nprof, 4),
@@ -626,7 +628,7 @@ def main():
             "host_binding": {k: binding.get(k) for k in ("bound", "affinity", "n_cpus", "numa_node", "bdf", "reason") if binding.get(k) is not None}})
 
     tim = profile(lambda n: run(h, n), h, nprof)
-    per_rank = rank_report(lat, own_elapsed, tim)
+    per_rank = rank_report(lat, own_elapsed, tim, own_close)
     pyramid_p2p = None
     if args.pyramid_both:  # the same job again with the exchange by peer writes: same frames, steps, barriers; every rank takes part
         h.close()
@@ -635,12 +637,12 @@ def main():
         for k in range(nslots):
             h.upload_frame(k, host_frames[k])
         e2, lat2 = timed(h, args.steps, args.warmup)
-        own2 = own[0]
+        own2, close2 = own[0], own[1]
         dump_joints(h, "pyramid_p2p")
         tim2 = profile(lambda n: run(h, n), h, nprof)
         pyramid_p2p = {"value": round(args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
                        "exchange": "peer writes over xGMI (exchange_kernel)",
-                       "latency_ms": latency_summary(lat2, args.steps), "per_rank": rank_report(lat2, own2, tim2)}
+                       "latency_ms": latency_summary(lat2, args.steps), "per_rank": rank_report(lat2, own2, tim2, close2)}
     out = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -110,7 +110,7 @@ def _check_self_explaining(d, n, same_device, replicas):
     assert [r["rank"] for r in pr] == list(range(n)) and len(d["ranks"]) == n
     for r in pr:
         assert r["frames_per_s"] > 0 and r["own_elapsed_s"] > 0 and r["latency_ms"]["p50"] > 0 and r["latency_ms"]["p95"] >= r["latency_ms"]["p50"]
-        assert abs(r["frames_per_s"] - d["steps"] / r["own_elapsed_s"]) <= 1e-2 * r["frames_per_s"]
+        assert abs(r["frames_per_s"] - d["steps"] / r["own_elapsed_s"]) <= 1e-2 * r["frames_per_s"] and r["closing_barrier_us"] >= 0
         assert 0 < r["conv_stack_ms"] <= r["frame_ms_hip_events"] * 1.05
         assert 800 < r["shader_clock_mhz"] < 2600, r        # MI355X: up to 2.4 GHz; the conv stack holds ~2.1 under load
         assert "bound" in r["host_binding"] and ("affinity" in r["host_binding"] or "reason" in r["host_binding"])

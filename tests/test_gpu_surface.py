@@ -679,4 +679,6 @@ def test_bench_line_contract():
     assert "probes_off=1" in d["build"] and "test_hooks=0" in d["build"] and d["n1_same_job"] is None
     pr = d["per_rank"]
     assert len(pr) == 1 and pr[0]["rank"] == 0 and 800 < pr[0]["shader_clock_mhz"] < 2600 and pr[0]["host_binding"]["bound"] is False
+    # `value` is K / (the frames' own time + the closing barrier + synchronize the contract puts inside the region)
+    assert abs(d["steps"] / (pr[0]["own_elapsed_s"] + pr[0]["closing_barrier_us"] * 1e-6) - d["value"]) <= 2e-3 * d["value"]
     assert d["rccl_ranks"] == 1 and d["ranks"][0]["device"] == 0 and d["launched_by"] == "single process"

@@ -334,3 +334,36 @@ print(json.dumps({"rep": rep, "now": sorted(os.sched_getaffinity(0))}))
     assert rep["bound"] is False and rep["reason"] == "--no-bind" and sorted(os.sched_getaffinity(0)) == avail
     rep = P.bind_rank(0, enable=True, sysfs=str(tmp_path / "nothing"))
     assert rep["bound"] is False and "no KFD" in rep["reason"] and sorted(os.sched_getaffinity(0)) == avail
+
+
+def test_rebind_when_hip_orders_devices_differently(tmp_path):
+    """bind_rank trusts the KFD node order; once HIP is up the rank knows its device's PCI bus.  If the two disagree, the calling thread is moved
+    to the right device's cores and the report says so (in a child process: the mask really changes)."""
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 2:
+        import pytest
+        pytest.skip("one core")
+    from vnect_amd import parallel as P
+    root = str(tmp_path / "sys")
+    lo, hi = avail[: len(avail) // 2], avail[len(avail) // 2:]
+    _fake_sysfs(root, [(0, 0x05, 0, 0, P.format_cpulist(lo), 0), (0, 0x85, 0, 0, P.format_cpulist(hi), 1)])
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+from vnect_amd import parallel as P
+rep = P.bind_rank(0, enable=True, sysfs=%r)          # KFD order says device 0 is bus 0x05 ...
+first = sorted(os.sched_getaffinity(0))
+rep = P.rebind_by_bus(rep, 0x85, sysfs=%r)           # ... HIP says this rank's device sits on bus 0x85
+same = P.rebind_by_bus(dict(rep), 0x85, sysfs=%r)    # (agreeing: nothing moves)
+odd = P.rebind_by_bus({"bound": True, "bdf": "0000:05:00.0"}, 0x33, sysfs=%r)
+print(json.dumps({"first": first, "now": sorted(os.sched_getaffinity(0)), "rep": rep, "same": same, "odd": odd}))
+""" % (ROOT, root, root, root, root)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["first"] == lo and out["now"] == hi
+    assert out["rep"]["rebound_after_hip_init"] is True and out["rep"]["bdf"] == "0000:85:00.0" and out["rep"]["bdf_is_the_hip_device"] is True
+    assert out["rep"]["numa_node"] == 1 and out["rep"]["affinity"] == P.format_cpulist(hi)
+    assert out["same"]["bdf_is_the_hip_device"] is True and out["same"]["affinity"] == P.format_cpulist(hi)
+    assert out["odd"]["bdf_is_the_hip_device"] is False and "matching device" in out["odd"]["rebind"]

@@ -9,7 +9,8 @@ an attribution of `value / N` against the job's own N = 1 loop (`n1_same_job`):
   clock   the conv stack got slower in step with the shader clock (eight GPUs share a node's power / cooling)
   device  the conv stack got slower at the same clock (memory / fabric contention between the ranks)
   host    the device frame time is unchanged, the gap between frames grew (launch path, CPU contention, a rank off its NUMA node)
-  rank    one rank is slower than the others (the barrier-to-barrier `value` waits for it)
+  rank    one rank is slower than the others (the barrier-to-barrier `value` waits for it: the other ranks' `closing` column -- the closing
+          barrier + synchronize of the timed region -- holds that wait)
 Thresholds are 2 %: anything below is called "none"."""
 import json
 import sys
@@ -32,13 +33,14 @@ def explain(d):
     pyramid = d.get("scaling") == "strong"
     out = ["N = %d (%s, backend %s): value %.1f frames/s%s" % (n, "pyramid: one stream over %d GPUs" % n if pyramid else "stream replicas",
                                                               d.get("backend"), d["value"], "" if pyramid else " = %.1f per GPU" % (d["value"] / n))]
-    out.append("  %4s %3s %9s %8s %8s %10s %9s %9s %9s  %s" % ("rank", "dev", "frames/s", "p50 ms", "p95 ms", "device ms", "conv ms", "clock", "host gap", "host thread"))
+    out.append("  %4s %3s %9s %8s %8s %10s %9s %9s %9s %9s  %s" % ("rank", "dev", "frames/s", "p50 ms", "p95 ms", "device ms", "conv ms", "clock", "host gap", "closing", "host thread"))
     for r in pr:
         gap = 1e3 / r["frames_per_s"] - r["frame_ms_hip_events"]
         hb = r.get("host_binding", {})
-        out.append("  %4d %3d %9.1f %8.4f %8.4f %10.4f %9.4f %9s %8.1fus  %s" % (
+        out.append("  %4d %3d %9.1f %8.4f %8.4f %10.4f %9.4f %9s %8.1fus %9s  %s" % (
             r["rank"], r["device"], r["frames_per_s"], r["latency_ms"]["p50"], r["latency_ms"]["p95"], r["frame_ms_hip_events"], r["conv_stack_ms"],
             ("%.0f" % r["shader_clock_mhz"]) if r.get("shader_clock_mhz") else "?", gap * 1e3,
+            ("%.0fus" % r["closing_barrier_us"]) if r.get("closing_barrier_us") is not None else "?",
             ("cores %s (NUMA %s)" % (hb.get("affinity"), hb.get("numa_node"))) if hb.get("bound") else "unbound: %s" % hb.get("reason")))
     n1 = d.get("n1_same_job")
     verdicts = []

@@ -306,3 +306,33 @@ def bind_rank(device, enable=True, sysfs="/sys"):
     now = sorted(os.sched_getaffinity(0))
     rep.update(bound=True, affinity=format_cpulist(now), n_cpus=len(now), narrowed_from=len(before))
     return rep
+
+
+def rebind_by_bus(report, pci_bus, sysfs="/sys"):
+    """After HIP is up: `pci_bus` is the PCI bus number HIP reports for this rank's device.  If the sysfs chain bound the process to ANOTHER
+    device's cores (HIP's device order differed from the KFD node order), bind the calling thread to the right ones now -- late for the
+    library's helper threads and first-touch allocations, in time for the thread that launches every kernel -- and say so in the report.
+    Returns the (updated) report; never raises."""
+    try:
+        if report.get("bdf") is None or pci_bus is None:
+            return report
+        report["bdf_is_the_hip_device"] = int(report["bdf"].split(":")[1], 16) == int(pci_bus)
+        if report["bdf_is_the_hip_device"] or not report.get("bound"):
+            return report
+        match = [b for b in gpu_bdfs(sysfs) if int(b.split(":")[1], 16) == int(pci_bus)]
+        if len(match) != 1:
+            report["rebind"] = "HIP reports bus 0x%02x: %d matching device(s) in sysfs, binding left as it is" % (int(pci_bus), len(match))
+            return report
+        d = os.path.join(sysfs, "bus", "pci", "devices", match[0])
+        local = parse_cpulist(open(os.path.join(d, "local_cpulist")).read())
+        # the mask was narrowed to the WRONG device's cores: the process's original mask is gone, so take the right device's local list as it is
+        os.sched_setaffinity(0, local)
+        now = sorted(os.sched_getaffinity(0))
+        report.update(bdf=match[0], affinity=format_cpulist(now), n_cpus=len(now), rebound_after_hip_init=True, bdf_is_the_hip_device=True)
+        try:
+            report["numa_node"] = int(open(os.path.join(d, "numa_node")).read().strip())
+        except (OSError, ValueError):
+            pass
+    except Exception as e:   # noqa: placement is an optimisation, never a reason to fail a job
+        report["rebind"] = "failed: %s" % e
+    return report
