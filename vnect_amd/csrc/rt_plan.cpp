@@ -562,6 +562,8 @@ int finalize_impl(vnect_handle* h)
         NEED(r);
         a = conv("res5b_branch2a_new", r, 1, 1, 256, true);
         NEED(a);
+        // (round 6, measured and dropped: in bf16 these two as ONE wide-tail launch on 32 x 128 tiles -- 50 workgroups owning all 128 mid
+        // channels of their rows -- take 10.9 us against 5.7 + 2.1 us and a boundary: NEGATIVE_RESULTS.md)
         b = conv("res5b_branch2b_new", a, 3, 1, 128, true);
         NEED(b);
         r = conv("res5b_branch2c_new", b, 1, 1, 256, true);
