@@ -588,8 +588,8 @@ int main(int argc, char** argv)
         CK(hipFree(dout));
     }
     // ---- second question: the small-N, long-K 1x1 launches (res4*_branch2a: M = 1 587, N = 256, K = 1 024; no shortcut) as 112 x 16 x 4 ----
-    {
-        const int N2 = 256, K = 1024;
+    for (int K : {1024, 2304}) {   // 2 304 = res4*_branch2b's K (3x3 x 256) as a plain GEMM: its K loop without the tap gather
+        const int N2 = 256;
         std::vector<float> hA((size_t)M * K), hW((size_t)N2 * K), hb(N2), hr((size_t)M * N2, 0.f), hout((size_t)M * N2);
         unsigned s = 777u;
         auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -620,8 +620,8 @@ int main(int argc, char** argv)
         CK(hipMemcpy(db, hb.data(), N2 * 4, hipMemcpyHostToDevice));
         CK(hipMemset(dr, 0, hr.size() * 4));
         a.A = dA, a.W = dW, a.bias = db, a.resid = dr, a.out = dout, a.M = M, a.N = N2, a.K = K;
-        printf("M = %d, N = %d, K = %d (res4*_branch2a; the product runs it as 200 tiles of 64 x 32 x 2: 9.5 us of execution, ~12.3 us per back-to-back launch): ideal %.2f us\n",
-               M, N2, K, 2.0 * M * N2 * K / 157.3e12 * 1e6);
+        printf("M = %d, N = %d, K = %d (%s; the product runs it as 200 tiles of 64 x 32 x 2: %s of execution + the 2.85-us boundary per back-to-back launch): ideal %.2f us\n",
+               M, N2, K, K == 1024 ? "res4*_branch2a" : "res4*_branch2b's K loop", K == 1024 ? "9.5 us" : "19.3 us", 2.0 * M * N2 * K / 157.3e12 * 1e6);
         for (int round = 0; round < 2; round++) {
             run<64, 5>("T64", a, reps, hout, ref, samples);    // (100 tiles of 64 x 64: the harness's yardstick, not a plan anybody would use)
             run_p<5>("P", a, reps, hout, ref, samples);
