@@ -169,7 +169,7 @@ def test_product_never_touches_the_oracle():
 
 
 def test_rccl_copy_already_mapped_is_reused(tmp_path):
-    """vnect_comm_library / load_rccl (runtime.cpp): a process that has a librccl.so mapped already -- torch.distributed's "nccl"
+    """vnect_comm_library / load_rccl (rt_comm.cpp): a process that has a librccl.so mapped already -- torch.distributed's "nccl"
     backend maps torch's bundled copy -- gets THAT copy (RTLD_NOLOAD: no second RCCL build in the process, nothing RTLD_GLOBAL);
     a process without one gets the ROCm copy through the library's RUNPATH.  Symbol lookup only: no GPU needed.  The same on the
     GPU with real communicators: tests/test_gpu_multirank.py."""

@@ -31,7 +31,7 @@ def test_conv_stack_every_layer(h3, weights, oracle_net):
     acts = ["conv1", "pool1"]
     for n in names:
         if "[" in n:                          # "<scope>[:N]": the first N channels of a paired launch's layer a as a launch of their own
-            continue                          # (runtime.cpp: head split) -- same tensor, listed with the pair
+            continue                          # (rt_plan.cpp: head split) -- same tensor, listed with the pair
         if "+" in n:                          # two layers in one launch: "<scope_a>+<rest of scope_b>"
             a, b = n.split("+")
             acts += [a, b if b.startswith("res") else a.split("_")[0] + "_" + b]
@@ -223,7 +223,7 @@ def test_fused_stem_fuzz_frame_shapes_and_scales(weights, monkeypatch):
 def test_pair_head_split(weights, oracle_net, monkeypatch):
     """res5a_branch2a_new + res5a_branch1_new (two 1x1 convs of res4f, vnect_model.py:168-175) at three scales in fp32: 600 tiles of 64 x 64
     are three rounds over 256 CUs for 2.34 rounds of matrix work, so the first 256 channels of branch2a run as a launch of their own (200
-    tiles of 64 x 32 with two K groups) and the pair keeps 500 tiles (runtime.cpp: add_conv_pair, plan::pair_head_cols).  Both launches
+    tiles of 64 x 32 with two K groups) and the pair keeps 500 tiles (rt_plan.cpp: add_conv_pair, plan::pair_head_cols).  Both launches
     write the same tensors: res5a_branch2a_new / res5a_branch1_new within 1e-4 of the oracle; against the single launch
     (VNECT_NO_HEAD_SPLIT=1) branch1 and channels 256.. of branch2a bit-identical (same tiles, same K order), channels ..255 equal to fp32
     rounding (two K groups: another summation order); bf16, a split-product handle and one or two scales keep the single launch."""

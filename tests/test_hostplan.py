@@ -2,7 +2,7 @@
 transposed conv's phase layout, the activation arena's first fit, the tile choice, the fused stem's row groups) behind its C shim
 (hostplan_capi.cpp), checked against the oracle's resizes and against index formulas written down here independently -- and the
 same tests once more under AddressSanitizer + UndefinedBehaviorSanitizer (test_hostplan_clean_under_asan_ubsan).  The code under
-test is what runtime.cpp compiles into libvnect_hip.so; the shim libraries are test infrastructure and never loaded by the product."""
+test is what the host runtime (rt_plan.cpp) compiles into libvnect_hip.so; the shim libraries are test infrastructure and never loaded by the product."""
 import ctypes as C
 import os
 import subprocess

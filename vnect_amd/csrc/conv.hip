@@ -422,7 +422,7 @@ __device__ __forceinline__ void tail_wide(const ConvArgs& a, const float* smem, 
     // Epilogue of a block, written for instruction count like the kernel's ordinary one (this code runs once per wave on a cold
     // instruction cache): shortcut / ReLU / output type are decided once per block (uniform branches around four-instruction rows),
     // the row base is a scalar pointer stepped by additions, the lane offset one 32-bit register.  Rows past M fall into the tensors'
-    // 64-pixel slack (runtime.cpp); columns past Nvalid are masked once.
+    // 64-pixel slack (rt_plan.cpp); columns past Nvalid are masked once.
     const bool t_of32 = !BF || a.out_f32;
     auto finish = [&](int cb, const f32x16& acc, float bias2, unsigned(&rw)[16]) __attribute__((always_inline)) {
         const int n2 = cb * 32 + col;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
         // chunk costs 4 DMA instructions and a few scalar adds -- no vector address arithmetic, no zero-page select.
         // Padded taps and rows past M use the buffer bounds check: such a lane's offset is 2^31 (>= num_records), the
         // hardware fetches nothing and writes zeros.  Negative tap offsets are folded into the descriptor's base
-        // (in - tap_bias), so the scalar offset is >= 0 (runtime.cpp).
+        // (in - tap_bias), so the scalar offset is >= 0 (rt_plan.cpp).
         __builtin_amdgcn_s_setprio(3);
         Prod p = p0;
         if constexpr (!SINGLE) p = load_prod();
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(512, (KG == 1 && BN <= 64) ? 4 : 2) void conv_strea
             // shortcut layers (os == 1).  Row r of the C layout is a UNIFORM distance from the lane's first row, so the
             // 16 requests share one 32-bit lane offset and differ in a scalar base: no address registers, no branches
             // (a branch per load would serialise the requests).  Rows past M fall into the tensors' 64-pixel slack
-            // (runtime.cpp), columns past Nvalid re-read column 0; both are masked at the store.
+            // (rt_plan.cpp), columns past Nvalid re-read column 0; both are masked at the store.
             const unsigned off = (unsigned)(mb * c.ldr + (n < c.Nvalid ? n : 0));
             if constexpr (BF) {
                 typedef __attribute__((address_space(1))) const unsigned short cgu16;
@@ -1869,7 +1869,7 @@ static hipError_t launch_stream(ConvArgs a, hipStream_t st)
 }
 
 // The three-accumulator shape is an optimisation with a working 64x64 fallback: if a toolchain ever allocates more than 256 registers or
-// spills for it, the library stays usable and the launch plan keeps the transposed conv on 64x64 tiles (runtime.cpp: choose_tile).
+// spills for it, the library stays usable and the launch plan keeps the transposed conv on 64x64 tiles (rt_plan.cpp: choose_tile).
 static bool g_deconv96 = false;
 bool conv_deconv96_available() { return g_deconv96; }
 

@@ -1,8 +1,8 @@
 // hostplan.h -- the pure-host planning logic of libvnect_hip.so: OpenCV-compatible resize tables, the merge / upsample tables of the
 // post-processing, weight packing into the kernels' layouts (incl. the transposed conv's four sub-pixel phases), the activation
 // arena's first-fit placement, the per-layer tile choice, and the fused stem's row groups.  Header-only and HIP-free on purpose:
-// runtime.cpp uses it for the product, and `make hostplan_asan` builds the same code with g++ -fsanitize=address,undefined behind a
-// small C shim (hostplan_capi.cpp) that tests/test_hostplan.py drives on the CPU box -- the ~2 000 lines of runtime.cpp otherwise
+// the host runtime (rt_plan.cpp, rt_exec.cpp) uses it for the product, and `make hostplan_asan` builds the same code with g++ -fsanitize=address,undefined behind a
+// small C shim (hostplan_capi.cpp) that tests/test_hostplan.py drives on the CPU box -- the ~2 000 lines of the runtime (rt_*.cpp) otherwise
 // only ever run next to a GPU.
 //
 // Reference arithmetic: cv2.resize(INTER_LINEAR) as used by /root/reference/src/utils.py:13-21 (via :107-150) and
@@ -413,7 +413,7 @@ inline TileChoice choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int n
     return c;
 }
 
-// ---- head split of a paired 1x1 launch (runtime.cpp: add_conv_pair) -------------------------------------
+// ---- head split of a paired 1x1 launch (rt_plan.cpp: add_conv_pair) -------------------------------------
 // A launch of T 64x64 tiles takes ceil(T / 256) block K loops per SIMD (a CU runs its tiles two at a time on the same four SIMDs); the
 // same columns as 64x32 tiles with two K groups take half a loop per round.  Returns how many leading channels of layer a to run as a
 // launch of their own (a multiple of 64 that choose_tile gives the 64x32x2 shape and ONE round), 0 if that does not beat the single

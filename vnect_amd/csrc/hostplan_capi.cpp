@@ -227,7 +227,7 @@ void hp_choose_tile(int M, int Nreal, int ntaps, int cpt, int K, int nphase, int
     const plan::TileChoice c = plan::choose_tile(M, Nreal, ntaps, cpt, K, nphase, bf16 != 0, name ? name : "", force, plan_s);
     out4[0] = c.BM, out4[1] = c.BN, out4[2] = c.KG, out4[3] = c.ks;
 }
-// the same with the transposed conv's three-accumulator shape allowed (what runtime.cpp passes for the fp32 instruction path)
+// the same with the transposed conv's three-accumulator shape allowed (what rt_plan.cpp passes for the fp32 instruction path)
 void hp_choose_tile96(int M, int Nreal, int ntaps, int cpt, int K, int nphase, int bf16, const char* name, const char* force, const char* plan_s,
                       int* out4)
 {

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_kernel(const StemArgs a)
 
     // PAIR: element offset (into the 64-channel output tensor) of the pixel behind each of the tile's up to 128 GEMM rows, one entry
     // per thread now instead of 16 divisions per lane later.  Rows past the tile point at the tensors' slack pixels (64 behind the
-    // last real one, runtime.cpp: never read), so that the stores need no per-row branch.
+    // last real one, rt_plan.cpp: never read), so that the stores need no per-row branch.
     unsigned* const pixtab = (unsigned*)((char*)smem + stem_lds<BF, FRAME>() - 512);
     if constexpr (PAIR) {
         if (tid < 128) {
