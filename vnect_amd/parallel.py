@@ -189,10 +189,9 @@ def parse_cpulist(text):
             continue
         if "-" in part:
             lo, hi = part.split("-", 1)
-            step = 1
             if ":" in hi:   # the kernel's "lo-hi:used/group" stride form does not occur for cpulists of a device; refuse it loudly
                 raise ValueError("strided cpulist %r" % part)
-            cpus.update(range(int(lo), int(hi) + 1, step))
+            cpus.update(range(int(lo), int(hi) + 1))
         else:
             cpus.add(int(part))
     return sorted(cpus)
