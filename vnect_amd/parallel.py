@@ -292,7 +292,10 @@ def bind_rank(device, enable=True, sysfs="/sys"):
         return {"bound": False, "reason": "no sched_getaffinity on this platform"}
     if not enable:
         return {"bound": False, "reason": "--no-bind", "affinity": format_cpulist(before), "n_cpus": len(before)}
-    b = rank_binding(device, sysfs=sysfs, allowed=before)
+    try:
+        b = rank_binding(device, sysfs=sysfs, allowed=before)
+    except Exception as e:   # noqa: placement is an optimisation -- an unreadable sysfs entry never stops a job
+        return {"bound": False, "reason": "sysfs: %s" % e, "affinity": format_cpulist(before), "n_cpus": len(before)}
     rep = {k: b[k] for k in ("bdf", "numa_node", "local_cpulist") if b.get(k) is not None}
     if not b["cpus"]:
         rep.update(bound=False, reason=b["reason"], affinity=format_cpulist(before), n_cpus=len(before))
