@@ -330,6 +330,12 @@ def main():
     if world != args.gpus:
         args.gpus = world  # the launcher's word counts
 
+    # N > 1 runs unattended: a rank that hangs (a collective one rank never joins, a peer that never writes) says WHERE -- every 5 minutes
+    # each rank dumps its Python stack to stderr until the job ends (the driver keeps the tail)
+    if world > 1:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("VNECT_BENCH_STACK_DUMP_S", "300")), repeat=True, exit=False)
+
     # Host placement FIRST, before this process imports torch or loads the HIP library (their helper threads and pinned allocations
     # inherit the mask): the cores local to this rank's GPU.  sysfs only, no GPU call (vnect_amd/parallel.py).
     from vnect_amd.parallel import bind_rank
@@ -778,6 +784,8 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     grp.close()
+    if world > 1:
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":
