@@ -25,6 +25,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     L = _native.lib()  # getattr on every symbol happens inside
     assert L.vnect_abi_version() == _native.ABI_VERSION
+    # ... and NOTHING else: the library's dynamic symbol table is the C ABI (csrc/vnect.map) -- kernel launchers, runtime internals and the
+    # kernels' host-side handles are local to it, so a host process cannot bind to (or collide with) anything but include/vnect_abi.h
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True)
+    if out.returncode == 0:
+        exported = {ln.split()[-1] for ln in out.stdout.splitlines() if ln.strip()}
+        assert exported == set(_native.SYMBOLS), exported ^ set(_native.SYMBOLS)
 
 
 def test_header_cites_reference_lines():
