@@ -212,3 +212,53 @@ def test_rccl_copy_already_mapped_is_reused(tmp_path):
     # ... and one that cannot be honoured is an error (VNECT_E_COMM), not a reason to pick another copy
     r = subprocess.run([sys.executable, "-c", code, "-"], capture_output=True, text=True, env=dict(env, VNECT_RCCL_LIB="/nonexistent/librccl.so"), timeout=300)
     assert r.returncode != 0 and "librccl.so not available" in r.stderr and "code %d" % _native.E_COMM in r.stderr, r.stderr[-800:]
+
+
+C_CALLER = r"""
+#include <stdio.h>
+#include <string.h>
+#include "vnect_abi.h"
+int main(void)
+{
+    vnect_config cfg;
+    vnect_handle* h = 0;
+    vnect_timings t;
+    int rc;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = 7;                                  /* a wrong size is refused before any device is touched */
+    rc = vnect_create(&cfg, &h);
+    printf("abi %d\n", vnect_abi_version());
+    printf("bad_create %d %s\n", rc, vnect_last_error(0));
+    printf("build %s\n", vnect_build_info());
+    t.struct_size = (int32_t)sizeof t;
+    printf("timings_null %d\n", vnect_get_timings(0, &t));
+    vnect_destroy(0);
+    return h != 0;
+}
+"""
+
+
+def test_a_plain_c_program_links_and_calls_the_abi(tmp_path):
+    """The boundary is a C ABI, not a Python extension: include/vnect_abi.h compiles as pedantic C99 (and C++11), and a C program linked
+    against libvnect_hip.so calls it with no Python, no torch and no GPU (it only exercises entry points that need none)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "caller.c"
+    src.write_text(C_CALLER)
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(_native.LIB_PATH)
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", lang, "-I", inc, str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (cc, r.stderr[-1500:])
+    exe = tmp_path / "caller"
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lvnect_hip", "-Wl,-rpath," + libdir,
+                        "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
+    out = dict(ln.split(" ", 1) for ln in r.stdout.strip().splitlines())
+    assert out["abi"] == str(_native.ABI_VERSION) and out["bad_create"].startswith("%d " % _native.E_ARG) and "struct_size" in out["bad_create"]
+    assert "probes_off=1" in out["build"] and out["timings_null"] == str(_native.E_ARG)
