@@ -623,6 +623,52 @@ def test_timings_carry_the_shader_clock_and_accept_the_v5_struct(weights):
     h.close()
 
 
+def test_a_c_program_runs_frames_through_the_abi(weights, tmp_path):
+    """The product path with NO Python in the process: tests/c/infer_frame.c (plain C99: vnect_create, 109 x vnect_set_weight,
+    vnect_finalize, vnect_infer per frame) linked against libvnect_hip.so, fed the weights and three frames through a flat file, prints
+    the joints as hex floats -- bit for bit what the ctypes path returns for the same frames and timestamps, fp32 and bf16."""
+    import shutil
+    import struct
+    import subprocess
+    from vnect_amd import _native
+    from tests import helpers
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_native.LIB_PATH)
+    exe = tmp_path / "infer_frame"
+    r = subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "infer_frame.c"),
+                        "-o", str(exe), "-L", libdir, "-lvnect_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    frames = [helpers.synth_frame(9500 + k, smooth=True) for k in range(3)]
+    blob = tmp_path / "in.bin"
+    with open(blob, "wb") as f:
+        f.write(struct.pack("<i", len(weights)))
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, np.float32)
+            f.write(struct.pack("<i", len(name)) + name.encode() + struct.pack("<i", a.ndim) + struct.pack("<%dq" % a.ndim, *a.shape) + a.tobytes())
+        f.write(struct.pack("<iii", len(frames), 368, 368))
+        for fr in frames:
+            f.write(np.ascontiguousarray(fr).tobytes())
+    for prec_name, prec in (("fp32", _native.FP32), ("bf16", _native.BF16)):
+        r = subprocess.run([str(exe), str(blob)] + (["bf16"] if prec_name == "bf16" else []), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+        lines = [ln.split() for ln in r.stdout.strip().splitlines() if ln.startswith("frame ")]
+        assert len(lines) == 3
+        h = _native.Handle(BASELINE_SCALES, precision=prec)
+        h.set_weights(weights)
+        h.finalize()
+        for k, ln in enumerate(lines):
+            vals = [float.fromhex(x) for x in ln[2:]]
+            c2 = np.array(vals[:42]).reshape(21, 2)
+            c3 = np.array(vals[42:], np.float32).reshape(21, 3)
+            t = 1.7e9 + k / 30.0
+            p2, p3 = h.infer(frames[k], t, t + 0.001)
+            assert np.array_equal(c2, p2) and np.array_equal(c3, p3), (prec_name, k)
+        h.close()
+
+
 # ------------------------------------------------------------------------------------------ the bench line's contract
 def test_bench_line_contract():
     """`python bench.py` as the driver runs it (N = 1): ONE JSON line on stdout with the contract's keys -- metric / value / unit /
